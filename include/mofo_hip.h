@@ -1,0 +1,122 @@
+/* libmofo_hip.so -- C-ABI of the MI355X-native MOFO / VideoMAE pretraining hot path.
+ *
+ * The reference (Moohnai/MOFO) has NO FFI / plugin layer for this path: it is plain Python on torch ops
+ * (SURVEY.md 8b).  This header therefore DEFINES the boundary a maintainer would bind (ctypes stub in
+ * INTEGRATION.md); each entry cites the reference arithmetic (file:line under /root/reference) it replaces.
+ *
+ * Contract for every entry:
+ *   - plain device pointers + explicit sizes / leading dimensions (in ELEMENTS) + a hipStream_t passed as void*;
+ *   - returns 0 (MOFO_OK) or a negative MOFO_E* code; never throws; mofo_last_error() has the text;
+ *   - never allocates, frees or synchronises; kernels are enqueued on the given stream;
+ *   - bf16 tensors are uint16_t bit patterns; "f32" = float; index tensors are int32.
+ * Built for gfx950 only.
+ */
+#ifndef MOFO_HIP_H
+#define MOFO_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MOFO_ABI_VERSION 1
+
+/* ---- library ---- */
+int mofo_version(void);
+const char* mofo_last_error(void);
+
+/* ---- GEMM family: modeling_finetune.py:45-49 (Mlp fc1/fc2), :84 (qkv F.linear), :96 (proj),
+ *      modeling_pretrain.py:124,157 (decoder head), :228,256 (encoder_to_decoder), and the Conv3d of
+ *      modeling_finetune.py:238-247 as a dot product per tubelet; plus their autograd dgrad / wgrad. ---- */
+enum { MOFO_GEMM_NT = 0, /* C[m,n] = sum_k A[m,k] B[n,k]  forward  */
+       MOFO_GEMM_NN = 1, /* C[m,n] = sum_k A[m,k] B[k,n]  dgrad    */
+       MOFO_GEMM_TN = 2  /* C[m,n] = sum_k A[k,m] B[k,n]  wgrad    */ };
+enum { MOFO_EPI_BF16 = 0,       /* C(bf16) = acc (+bias[n])                                            */
+       MOFO_EPI_BIAS_GELU = 1,  /* h = acc+bias; C(bf16)=h; C2(bf16)=gelu_erf(h)   (fc1 + nn.GELU)      */
+       MOFO_EPI_RESID_F32 = 2,  /* C(f32) = resid(f32) + acc (+bias)   (proj / fc2 + residual add)      */
+       MOFO_EPI_POS_F32 = 3,    /* C(f32)[rowmap(m)] = acc (+bias) + pos[row_idx[m]]  (patch-embed / e2d)*/
+       MOFO_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * gelu_erf'(aux[m,n])   (backward through nn.GELU)     */
+       MOFO_EPI_F32 = 5         /* C(f32) = acc, or += (atomic) when splits>1 or accumulate!=0          */ };
+typedef struct mofo_gemm_args {
+    int op, epilogue;
+    int M, N, K;                  /* C is MxN, reduction length K */
+    const void* A; int lda;       /* bf16 */
+    const void* B; int ldb;       /* bf16 */
+    void* C; int ldc;
+    void* C2; int ldc2;           /* BIAS_GELU second output */
+    const float* bias;            /* [N] or NULL */
+    const float* resid; int ldr;  /* RESID_F32 */
+    const void* aux; int ldaux;   /* DGELU: pre-activation h (bf16) */
+    const float* pos; int ldpos;  /* POS_F32: table rows */
+    const int* row_idx;           /* POS_F32: [M] table row per output row */
+    int rows_in, rows_out, row_off; /* POS_F32: out row = (m / rows_in) * rows_out + row_off + m % rows_in */
+    int splits;                   /* split the reduction over gridDim.z (F32 epilogue only) */
+    int accumulate;               /* F32 epilogue: add into C instead of overwrite */
+} mofo_gemm_args;
+int mofo_gemm(const mofo_gemm_args* args, void* stream);
+
+/* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */
+int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* stream);   /* out must be zeroed */
+
+/* ---- LayerNorm (eps inside sqrt, biased variance): modeling_finetune.py:200,206,218-219; modeling_pretrain.py:51,95,123,157.
+ * Row r of the (M x D) problem reads/writes x row  (r / rows_in) * rows_out + row_off + r % rows_in  (pass rows_in=M,
+ * rows_out=M, row_off=0 for the identity map; the decoder's final norm uses the last N_mask rows of every clip). ---- */
+int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float eps, int M, int D,
+                       int rows_in, int rows_out, int row_off,
+                       void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
+/* dx(f32) = dres (f32, may be NULL) + LN'(dy); dx_bf16 (may be NULL) = bf16 copy; dw/db accumulate (+=, atomics). */
+int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const float* x, int ldx, const float* w,
+                       const float* mean, const float* rstd, const float* dres, int lddres, int M, int D,
+                       int rows_in, int rows_out, int row_off,
+                       float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db, void* stream);
+
+/* ---- multi-head self-attention core: modeling_finetune.py:85-95 (q*scale, q@k^T, softmax, @v).
+ * qkv is the fused projection output, bf16 [B*N, 3*H*64] (q | k | v, each head-major x 64); head_dim is 64 in every
+ * configuration of the reference.  out bf16 [B*N, H*64]; lse2 f32 [B,H,N] = log2-sum-exp2 of (scale*log2e*scores). ---- */
+int mofo_attention_fwd(const void* qkv, int ldqkv, int B, int N, int H, float scale,
+                       void* out, int ldo, float* lse2, void* stream);
+/* dqkv bf16 [B*N, 3*H*64] (same layout as qkv); delta f32 [B,H,N] is scratch written by the call. */
+int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
+                       const float* lse2, int B, int N, int H, float scale,
+                       void* dqkv, int lddqkv, float* delta, void* stream);
+
+/* ---- masks -> index lists: replaces the boolean gathers x[~mask] / pos[mask] of modeling_pretrain.py:90,261-262
+ * and engine_for_pretraining.py:63 (which cost a device->host sync in the reference).  mask: uint8 [B,N], 1 = masked.
+ * vis_idx [B,n_vis], msk_idx [B,N-n_vis]: ascending token ids per clip.  status[0] |= 1 if a clip's count differs. ---- */
+int mofo_mask_to_indices(const uint8_t* mask, int B, int N, int n_vis, int* vis_idx, int* msk_idx, int* status, void* stream);
+
+/* ---- tubelet gather for PatchEmbed over VISIBLE tokens only: modeling_finetune.py:238-248 + modeling_pretrain.py:90.
+ * clips f32 [B,C,T,H,W]; token id = t*(H/p)*(W/p) + h*(W/p) + w; out bf16 [B*n_tok, C*pt*p*p], column order (c,pt,ph,pw)
+ * = Conv3d weight order.  The GEMM (NT, POS_F32 epilogue) against proj.weight.view(D,-1) finishes PatchEmbed + pos. ---- */
+int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int pt, int p,
+                      const int* tok_idx, int n_tok, void* out_bf16, int ldo, void* stream);
+
+/* ---- decoder input assembly: modeling_pretrain.py:260-263.  Writes the masked half of x_full (f32 [B,N,D]):
+ * x_full[b, n_vis + j] = mask_token + pos[msk_idx[b,j]]  (the visible half is the e2d GEMM's POS_F32 epilogue). ---- */
+int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx,
+                          int B, int N, int n_vis, int D, float* x_full, void* stream);
+/* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows. */
+int mofo_assemble_bwd(const float* dx_full, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token, void* stream);
+
+/* ---- reconstruction target + MSE: engine_for_pretraining.py:43-63 (un-normalise, patchify (p0 p1 p2) c,
+ * per-(token,channel) standardise with UNBIASED var and 1e-6 after the sqrt, gather masked) and :27,67 (nn.MSELoss).
+ * pred bf16 [B*n_msk, C*pt*p*p] (feature order (pt,ph,pw,c)); row_loss f32 [B*n_msk] scratch; loss f32 [1];
+ * dpred bf16 (may be NULL) = grad_scale * 2*(pred-target)/numel.  normalize=0 -> raw pixel targets (:59-60). ---- */
+int mofo_target_mse(const float* clips, int B, int C, int T, int H, int W, int pt, int p,
+                    const int* msk_idx, int n_msk, const void* pred, int ldp, int normalize, float grad_scale,
+                    float* row_loss, float* loss, void* dpred, int lddp, void* target_out_f32, void* stream);
+
+/* ---- optimizer side on FLAT buffers: utils.py:376-388 (global grad L2 norm), torch.nn.utils.clip_grad_norm_
+ * (utils.py:359), torch.optim.AdamW as configured by optim_factory.py:91-127 (two param groups: decayed / not decayed).
+ * n is a multiple of 1024; chunk c covers elements [1024c, 1024c+1024); chunk_group[c] (0/1) selects (lr0,wd0) or
+ * (lr1,wd1).  partial f32 [>= 1024] scratch.  If max_norm > 0 the gradient is scaled by min(1, max_norm/(norm+1e-6))
+ * with norm read from grad_norm[0] on the device (no host sync). ---- */
+int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, void* stream);
+int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+               float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+               const float* grad_norm, float max_norm, float grad_mult, void* stream);
+int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

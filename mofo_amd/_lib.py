@@ -1,0 +1,73 @@
+"""ctypes binding of libmofo_hip.so (the C-ABI declared in include/mofo_hip.h).
+
+There is NO CPU fallback: if the shared library is missing or a call fails, this raises.  Import torch first so
+that the HIP runtime this library binds to (libamdhip64.so.7) is the one torch already loaded.
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (loads libamdhip64 before our library)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmofo_hip.so")
+
+# enums (mirror include/mofo_hip.h)
+GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+EPI_BF16, EPI_BIAS_GELU, EPI_RESID_F32, EPI_POS_F32, EPI_DGELU_BF16, EPI_F32 = 0, 1, 2, 3, 4, 5
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("op", _i), ("epilogue", _i), ("M", _i), ("N", _i), ("K", _i),
+                ("A", _vp), ("lda", _i), ("B", _vp), ("ldb", _i), ("C", _vp), ("ldc", _i), ("C2", _vp), ("ldc2", _i),
+                ("bias", _vp), ("resid", _vp), ("ldr", _i), ("aux", _vp), ("ldaux", _i),
+                ("pos", _vp), ("ldpos", _i), ("row_idx", _vp), ("rows_in", _i), ("rows_out", _i), ("row_off", _i),
+                ("splits", _i), ("accumulate", _i)]
+
+
+_SIGS = {
+    "mofo_version": (_i, []),
+    "mofo_last_error": (C.c_char_p, []),
+    "mofo_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
+    "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
+    "mofo_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
+    "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mofo_patch_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
+    "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mofo_target_mse": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mofo_sumsq": (_i, [_vp, _ll, _vp, _vp, _vp]),
+    "mofo_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),
+    "mofo_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def load():
+    """Return the loaded library; raise (never fall back) if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is not built -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(mofo_amd has no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        if lib.mofo_version() != 1:
+            raise RuntimeError("libmofo_hip.so ABI version mismatch")
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mofo_last_error().decode(errors="replace")
+        raise RuntimeError(f"libmofo_hip {what} failed with code {rc}: {msg}")

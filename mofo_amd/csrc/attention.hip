@@ -1,0 +1,380 @@
+// Fused multi-head self-attention for gfx950, head_dim 64 (every ViT config of the reference), bf16 in / f32 accumulate.
+// Replaces modeling_finetune.py:85-95 (q*scale; q@k^T; softmax; @v) and its autograd backward; the [B,H,N,N]
+// score / probability tensors of the reference are never materialised.
+//
+// All three kernels use v_mfma_f32_32x32x16_bf16 with the "other" sequence index on the LANE:
+//   fwd / dQ : S^T[key][query] = K . Q^T    -> each lane owns one query column: row-softmax is in-lane + one half swap
+//   dK,dV    : S  [query][key] = Q . K^T    -> each lane owns one key column
+// so the f32 accumulator of the first product is, after a bf16 pack, directly the B operand of the second product
+// (k index permuted as the accumulator rows are: element j of lane half h <-> row 16s + 8(j>>2) + 4h + (j&3));
+// the matching A operand (V^T, K^T, dO^T, Q^T) comes from the row-major LDS tile through ds_read_b64_tr_b16.
+// K/V (or Q/dO) tiles of 32 rows are register-staged into a 2-deep LDS ring: one barrier per tile.
+#include "common.h"
+#include "../../include/mofo_hip.h"
+
+namespace {
+
+constexpr int HD = 64;
+constexpr int RS = 144;              // LDS row stride in bytes: 128 B of data + 16 B pad (b128 row reads conflict-free)
+constexpr int TILE = 32 * RS;        // one 32-row tile
+constexpr float NEG_BIG = -1.0e30f;
+
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// A operand = rows of a [32][64] LDS tile: A[row = lane&31][k = 16 ks + 8 hh + j]
+__device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int ks, int lane) {
+    return *(const bf16x8*)(tile + (lane & 31) * RS + (16 * ks + 8 * (lane >> 5)) * 2);
+}
+
+// A operand = TRANSPOSE of a [32 seq][64 d] LDS tile for k-step s2 (16 seq rows) and d-tile dt (32 d):
+// A[row = d = 32 dt + (lane&31)][slot (hh, j)] = tile[seq = 16 s2 + 8 (j>>2) + 4 hh + (j&3)][d]
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int s2, int dt, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hh = lane >> 5;
+    const unsigned char* a0 = tile + (16 * s2 + 4 * hh + q) * RS + (32 * dt + 16 * (g & 1) + 4 * pp) * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0 + 8 * RS));
+    s16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+// pack accumulator registers 8 s .. 8 s + 7 into the B fragment of k-step s
+__device__ __forceinline__ bf16x8 pack_frag(const float* p, int s) {
+    bf16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (__bf16)p[8 * s + j];
+    return f;
+}
+
+// store an accumulator tile pair D[d][seq] (seq on the lane) as bf16 rows dst[seq][d], scaled
+__device__ __forceinline__ void store_T(bf16_t* dst_row, const f32x16& a0, const f32x16& a1, float mul, int hh) {
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& a = dt ? a1 : a0;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            u32x2 o = {pack_bf16x2(a[4 * rg] * mul, a[4 * rg + 1] * mul), pack_bf16x2(a[4 * rg + 2] * mul, a[4 * rg + 3] * mul)};
+            *(u32x2*)(dst_row + 32 * dt + 8 * rg + 4 * hh) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+// MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
+template <int NW, int MODE>
+__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int N, int H, float c,
+                                                          float scale, bf16_t* __restrict__ out, int ldo,
+                                                          float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
+                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int D = H * HD;
+    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const bf16_t* base = qkv + (size_t)b * N * ldqkv;
+    const bf16_t* qp = base + h * HD;
+    const bf16_t* kp = base + D + h * HD;
+    const bf16_t* vp = base + 2 * D + h * HD;
+    const int qi = q0 + (lane & 31);
+    const int qrow = qi < N ? qi : N - 1;
+    const bool qvalid = qi < N;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(qp + (size_t)qrow * ldqkv + 16 * ks + 8 * hh);
+
+    bf16x8 dof[4];
+    float L2 = 0.f, dl = 0.f;
+    if constexpr (MODE == 1) {
+        const bf16_t* dop = dout + ((size_t)b * N + qrow) * lddo + h * HD;
+        const bf16_t* op = out + ((size_t)b * N + qrow) * ldo + h * HD;
+        float part = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            dof[ks] = *(const bf16x8*)(dop + 16 * ks + 8 * hh);
+            const bf16x8 ov = *(const bf16x8*)(op + 16 * ks + 8 * hh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) part += (float)dof[ks][j] * (float)ov[j];
+        }
+        dl = part + __shfl_xor(part, 32, 64);
+        L2 = lse2[((size_t)b * H + h) * N + qrow];
+        if (qvalid && hh == 0) delta[((size_t)b * H + h) * N + qi] = dl;
+    }
+
+    f32x16 o0 = zero16(), o1 = zero16();
+    float m = NEG_BIG, l = 0.f;
+
+    const int nkt = (N + 31) >> 5;
+    u32x4 kreg = {0, 0, 0, 0}, vreg = {0, 0, 0, 0};
+    auto gload = [&](int kt) {
+        if (tid < 256) {
+            int r = kt * 32 + (tid >> 3);
+            r = r < N ? r : N - 1;
+            const size_t off = (size_t)r * ldqkv + (tid & 7) * 8;
+            kreg = *(const u32x4*)(kp + off);
+            vreg = *(const u32x4*)(vp + off);
+        }
+    };
+    auto lwrite = [&](int buf) {
+        if (tid < 256) {
+            unsigned char* d = smem + buf * 2 * TILE + (tid >> 3) * RS + (tid & 7) * 16;
+            *(u32x4*)d = kreg;
+            *(u32x4*)(d + TILE) = vreg;
+        }
+    };
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    if (nkt > 1) gload(1);
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const unsigned char* Kt = smem + (kt & 1) * 2 * TILE;
+        const unsigned char* Vt = Kt + TILE;
+        f32x16 s = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, ks, lane), qf[ks], s, 0, 0, 0);
+        const bool tail = (kt * 32 + 32 > N);
+        float p[16];
+        if constexpr (MODE == 0) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = s[r] * c;
+                if (tail && (kt * 32 + acc_row(r, hh) >= N)) x = NEG_BIG;
+                p[r] = x;
+                mx = fmaxf(mx, x);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = fast_exp2(m - mn);
+            float ls = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = fast_exp2(p[r] - mn);
+                ls += p[r];
+            }
+            l = l * alpha + ls;
+            m = mn;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                o0[r] *= alpha;
+                o1[r] *= alpha;
+            }
+            const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 0, lane), pf0, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 0, lane), pf1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 1, lane), pf0, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 1, lane), pf1, o1, 0, 0, 0);
+        } else {
+            f32x16 dp = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, ks, lane), dof[ks], dp, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = fast_exp2(s[r] * c - L2);
+                if (tail && (kt * 32 + acc_row(r, hh) >= N)) pr = 0.f;
+                p[r] = pr * (dp[r] - dl);
+            }
+            const bf16x8 f0 = pack_frag(p, 0), f1 = pack_frag(p, 1);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 0, lane), f0, o0, 0, 0, 0);
+            o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 0, lane), f1, o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 1, lane), f0, o1, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 1, lane), f1, o1, 0, 0, 0);
+        }
+        if (kt + 1 < nkt) lwrite((kt + 1) & 1);
+        __syncthreads();
+        if (kt + 2 < nkt) gload(kt + 2);
+    }
+
+    if (!qvalid) return;
+    if constexpr (MODE == 0) {
+        const float lt = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / lt;
+        store_T(out + ((size_t)b * N + qi) * ldo + h * HD, o0, o1, inv, hh);
+        if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m + fast_log2(lt);
+    } else {
+        store_T(dqkv + ((size_t)b * N + qi) * lddqkv + h * HD, o0, o1, scale, hh);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ dK, dV
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int N, int H, float c,
+                                                            float scale, const bf16_t* __restrict__ dout, int lddo,
+                                                            const float* __restrict__ lse2, const float* __restrict__ delta,
+                                                            bf16_t* __restrict__ dqkv, int lddqkv) {
+    // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
+    constexpr int BUF = 2 * TILE + 256;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int D = H * HD;
+    const int k0 = (blockIdx.x * NW + wave) * 32;
+    const bf16_t* base = qkv + (size_t)b * N * ldqkv;
+    const bf16_t* qp = base + h * HD;
+    const bf16_t* kp = base + D + h * HD;
+    const bf16_t* vp = base + 2 * D + h * HD;
+    const bf16_t* dop = dout + (size_t)b * N * lddo + h * HD;
+    const float* lp = lse2 + ((size_t)b * H + h) * N;
+    const float* dp_ = delta + ((size_t)b * H + h) * N;
+    const int ki = k0 + (lane & 31);
+    const int krow = ki < N ? ki : N - 1;
+
+    bf16x8 kf[4], vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        kf[ks] = *(const bf16x8*)(kp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
+        vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
+    }
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
+
+    const int nqt = (N + 31) >> 5;
+    u32x4 qreg = {0, 0, 0, 0}, oreg = {0, 0, 0, 0};
+    float sreg = 0.f;
+    auto gload = [&](int qt) {
+        if (tid < 256) {
+            int r = qt * 32 + (tid >> 3);
+            r = r < N ? r : N - 1;
+            qreg = *(const u32x4*)(qp + (size_t)r * ldqkv + (tid & 7) * 8);
+            oreg = *(const u32x4*)(dop + (size_t)r * lddo + (tid & 7) * 8);
+            if (tid < 64) {
+                const int qq = qt * 32 + (tid & 31);
+                // a query row beyond N must contribute nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
+                if (tid < 32) sreg = qq < N ? lp[qq] : 1.0e30f;
+                else sreg = qq < N ? dp_[qq] : 0.f;
+            }
+        }
+    };
+    auto lwrite = [&](int buf) {
+        if (tid < 256) {
+            unsigned char* d = smem + buf * BUF + (tid >> 3) * RS + (tid & 7) * 16;
+            *(u32x4*)d = qreg;
+            *(u32x4*)(d + TILE) = oreg;
+            if (tid < 64) *(float*)(smem + buf * BUF + 2 * TILE + tid * 4) = sreg;
+        }
+    };
+    gload(0);
+    lwrite(0);
+    __syncthreads();
+    if (nqt > 1) gload(1);
+
+    for (int qt = 0; qt < nqt; ++qt) {
+        const unsigned char* Qt = smem + (qt & 1) * BUF;
+        const unsigned char* Ot = Qt + TILE;
+        const float* Lt = (const float*)(Qt + 2 * TILE);
+        const float* Dt = Lt + 32;
+        f32x16 s = zero16(), dpv = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), kf[ks], s, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
+        float p[16], ds[16];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+            const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rg + e;
+                const float pr = fast_exp2(s[r] * c - lv[e]);
+                p[r] = pr;
+                ds[r] = pr * (dpv[r] - dv[e]);
+            }
+        }
+        const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+        const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 0, lane), pf0, dv0, 0, 0, 0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 0, lane), pf1, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 1, lane), pf0, dv1, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 1, lane), pf1, dv1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 0, lane), sf0, dk0, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
+        if (qt + 1 < nqt) lwrite((qt + 1) & 1);
+        __syncthreads();
+        if (qt + 2 < nqt) gload(qt + 2);
+    }
+    if (ki >= N) return;
+    bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
+    store_T(drow + D, dk0, dk1, scale, hh);
+    store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
+}
+
+int pick_nw(int N) {
+    const int t = (N + 31) / 32;  // 32-row wave tiles
+    if (t % 7 == 0) return 7;
+    if (t % 5 == 0) return 5;
+    return 4;
+}
+
+}  // namespace
+
+#define LAUNCH_Q(NW, MODE)                                                                                              \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE>), dim3(ceil_div(N, 32 * NW), H, B), dim3(NW * 64), 0, s, (const bf16_t*)qkv, \
+                       ldqkv, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
+
+static int check_common(const char* who, const void* qkv, int ldqkv, int B, int N, int H) {
+    if (!qkv) MOFO_FAIL(MOFO_EINVAL, "%s: null qkv", who);
+    if (B <= 0 || N <= 0 || H <= 0) MOFO_FAIL(MOFO_EINVAL, "%s: bad dims B=%d N=%d H=%d", who, B, N, H);
+    if (ldqkv < 3 * H * 64 || ldqkv % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: ldqkv=%d must be >= 3*H*64 and a multiple of 8", who, ldqkv);
+    if (H > 65535 || B > 65535) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: grid too large", who);
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_fwd(const void* qkv, int ldqkv, int B, int N, int H, float scale, void* out, int ldo,
+                                  float* lse2, void* stream) {
+    int rc = check_common("mofo_attention_fwd", qkv, ldqkv, B, N, H);
+    if (rc) return rc;
+    if (!out || !lse2) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_fwd: null output");
+    if (ldo < H * 64 || ldo % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd: bad ldo=%d", ldo);
+    hipStream_t s = (hipStream_t)stream;
+    const float c = scale * 1.4426950408889634f;
+    const void* dout = nullptr; int lddo = 0; void* dqkv = nullptr; int lddqkv = 0; float* delta = nullptr;
+    switch (pick_nw(N)) {
+        case 7: LAUNCH_Q(7, 0); break;
+        case 5: LAUNCH_Q(5, 0); break;
+        default: LAUNCH_Q(4, 0); break;
+    }
+    MOFO_CHECK_LAUNCH("mofo_attention_fwd");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
+                                  const float* lse2_in, int B, int N, int H, float scale, void* dqkv, int lddqkv,
+                                  float* delta, void* stream) {
+    int rc = check_common("mofo_attention_bwd", qkv, ldqkv, B, N, H);
+    if (rc) return rc;
+    if (!out || !dout || !lse2_in || !dqkv || !delta) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_bwd: null pointer");
+    if (ldo % 8 || lddo % 8 || lddqkv % 4 || lddqkv < 3 * H * 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_bwd: bad leading dims");
+    hipStream_t s = (hipStream_t)stream;
+    const float c = scale * 1.4426950408889634f;
+    float* lse2 = const_cast<float*>(lse2_in);
+    const int nw = pick_nw(N);
+    switch (nw) {
+        case 7: LAUNCH_Q(7, 1); break;
+        case 5: LAUNCH_Q(5, 1); break;
+        default: LAUNCH_Q(4, 1); break;
+    }
+    MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
+#define LAUNCH_KV(NW)                                                                                                  \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW>), dim3(ceil_div(N, 32 * NW), H, B), dim3(NW * 64), 0, s, (const bf16_t*)qkv, \
+                       ldqkv, N, H, c, scale, (const bf16_t*)dout, lddo, (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
+    switch (nw) {
+        case 7: LAUNCH_KV(7); break;
+        case 5: LAUNCH_KV(5); break;
+        default: LAUNCH_KV(4); break;
+    }
+    MOFO_CHECK_LAUNCH("mofo_attention_bwd(dkdv)");
+    return MOFO_OK;
+}

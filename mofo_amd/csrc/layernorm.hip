@@ -1,0 +1,189 @@
+// LayerNorm forward / backward for the fp32 residual stream (gfx950).  HBM-bound: one wave per row, 16-B loads,
+// statistics in fp32 by wave shuffles.  Replaces nn.LayerNorm(eps=1e-6) at modeling_finetune.py:200,206,218-219 and
+// modeling_pretrain.py:51,95,123,157 and its autograd backward.
+#include "common.h"
+#include "../../include/mofo_hip.h"
+
+namespace {
+
+constexpr int MAX_IT = 4;  // D <= 1024
+
+__device__ __forceinline__ size_t map_row(int r, int rows_in, int rows_out, int row_off) {
+    return (size_t)(r / rows_in) * rows_out + row_off + (r % rows_in);
+}
+
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                      const float* __restrict__ b, float eps, int M, int D, int rows_in,
+                                                      int rows_out, int row_off, bf16_t* __restrict__ y, int ldy,
+                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave;
+    if (r >= M) return;
+    const float* xr = x + map_row(r, rows_in, rows_out, row_off) * ldx;
+    f32x4 v[NIT];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        v[it] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+    }
+    const float mu = wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = v[it][e] - mu;
+                q += d * d;
+            }
+        }
+    }
+    const float rs = rsqrtf(wave_sum(q) / D + eps);
+    if (lane == 0) {
+        mean[r] = mu;
+        rstd[r] = rs;
+    }
+    bf16_t* yr = y + (size_t)r * ldy;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        if (c < D) {
+            const f32x4 wv = *(const f32x4*)(w + c);
+            const f32x4 bv = *(const f32x4*)(b + c);
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * wv[e] + bv[e];
+            u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *(u32x2*)(yr + c) = pk;
+        }
+    }
+}
+
+template <int NIT>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ x,
+                                                      int ldx, const float* __restrict__ w, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                      int lddres, int M, int D, int rows_in, int rows_out, int row_off,
+                                                      float* __restrict__ dx, int lddx, bf16_t* __restrict__ dxb, int lddxb,
+                                                      float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[2][4][MAX_IT * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    f32x4 wv[NIT], aw[NIT], ab[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int c = (it * 64 + lane) * 4;
+        wv[it] = c < D ? *(const f32x4*)(w + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        aw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        ab[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
+        const size_t xr = map_row(r, rows_in, rows_out, row_off);
+        const float mu = mean[r], rs = rstd[r];
+        f32x4 xh[NIT], g[NIT];
+        float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                const f32x4 xv = *(const f32x4*)(x + xr * ldx + c);
+                const u32x2 dv = *(const u32x2*)(dy + (size_t)r * lddy + c);
+                const float d[4] = {bf16lo_to_f32(dv[0]), bf16hi_to_f32(dv[0]), bf16lo_to_f32(dv[1]), bf16hi_to_f32(dv[1])};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xh[it][e] = (xv[e] - mu) * rs;
+                    g[it][e] = d[e] * wv[it][e];
+                    c1 += g[it][e];
+                    c2 += g[it][e] * xh[it][e];
+                    aw[it][e] += d[e] * xh[it][e];
+                    ab[it][e] += d[e];
+                }
+            } else {
+                xh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                g[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        c1 = wave_sum(c1) / D;
+        c2 = wave_sum(c2) / D;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int c = (it * 64 + lane) * 4;
+            if (c < D) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
+                if (dres) o += *(const f32x4*)(dres + xr * lddres + c);
+                *(f32x4*)(dx + xr * lddx + c) = o;
+                if (dxb) {
+                    u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                    *(u32x2*)(dxb + xr * lddxb + c) = pk;
+                }
+            }
+        }
+    }
+    // block reduce of the parameter-gradient partials, then one atomic per column per block
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            red[0][wave][(it * 64 + lane) * 4 + e] = aw[it][e];
+            red[1][wave][(it * 64 + lane) * 4 + e] = ab[it][e];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        const float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
+        const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
+        atomicAdd(dw + c, sw);
+        atomicAdd(db + c, sb);
+    }
+}
+
+}  // namespace
+
+static int ln_check(const char* who, int M, int D, int rows_in, int rows_out) {
+    if (M <= 0 || D <= 0) MOFO_FAIL(MOFO_EINVAL, "%s: bad dims M=%d D=%d", who, M, D);
+    if (D % 4 || D > 1024) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: D=%d must be a multiple of 4 and <= 1024", who, D);
+    if (rows_in <= 0 || rows_out < rows_in) MOFO_FAIL(MOFO_EINVAL, "%s: bad row map", who);
+    return MOFO_OK;
+}
+
+extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float eps, int M, int D,
+                                  int rows_in, int rows_out, int row_off, void* y, int ldy, float* mean, float* rstd,
+                                  void* stream) {
+    if (!x || !w || !b || !y || !mean || !rstd) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_fwd: null pointer");
+    int rc = ln_check("mofo_layernorm_fwd", M, D, rows_in, rows_out);
+    if (rc) return rc;
+    if (ldx % 4 || ldy % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_fwd: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const int nit = ceil_div(D, 256);
+    dim3 grid(ceil_div(M, 4)), block(256);
+#define GO(N_) hipLaunchKernelGGL((ln_fwd_kernel<N_>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd)
+    switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
+#undef GO
+    MOFO_CHECK_LAUNCH("mofo_layernorm_fwd");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
+                                  const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
+                                  int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
+    int rc = ln_check("mofo_layernorm_bwd", M, D, rows_in, rows_out);
+    if (rc) return rc;
+    if (lddy % 4 || ldx % 4 || lddx % 4 || (dres && lddres % 4) || (dxb && lddxb % 4))
+        MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_bwd: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const int nit = ceil_div(D, 256);
+    int blocks = ceil_div(M, 4);
+    if (blocks > 1024) blocks = 1024;
+    dim3 grid(blocks), block(256);
+#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db)
+    switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
+#undef GO
+    MOFO_CHECK_LAUNCH("mofo_layernorm_bwd");
+    return MOFO_OK;
+}

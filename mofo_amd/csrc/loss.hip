@@ -1,0 +1,145 @@
+// Fused reconstruction-target builder + MSE loss + d(loss)/d(pred)  (gfx950, HBM-bound).
+// Replaces engine_for_pretraining.py:43-63 (un-normalise with the ImageNet constants, patchify `(p0 p1 p2) c`,
+// per-(token,channel) standardise over 512 pixels with the UNBIASED variance and 1e-6 added after the sqrt, gather the
+// masked tokens) and :27,67 (nn.MSELoss, mean over every element) in ONE pass over the masked 90 % of the clip:
+// the [B,1568,1536] f32 target tensor of the reference is never written.
+// One wave per masked token: lane e and e+64 each own one float4 (4 pixels of one image-row segment) per channel,
+// i.e. 12 consecutive prediction features (4 pixels x 3 channels, channel fastest).
+#include "common.h"
+#include "../../include/mofo_hip.h"
+
+namespace {
+
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};  // IMAGENET_DEFAULT_MEAN (engine_for_pretraining.py:45)
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};   // IMAGENET_DEFAULT_STD  (:46)
+
+__global__ __launch_bounds__(256) void target_mse_kernel(const float* __restrict__ clips, int T, int H, int W,
+                                                         const int* __restrict__ msk_idx, int n_msk, int rows,
+                                                         const bf16_t* __restrict__ pred, int ldp, int normalize, float gs,
+                                                         float* __restrict__ row_loss, bf16_t* __restrict__ dpred, int lddp,
+                                                         float* __restrict__ target_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / n_msk;
+    const int tok = msk_idx[row];
+    const int gw = W >> 4, gh = H >> 4;
+    const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
+    const float* cb = clips + (size_t)b * 3 * T * H * W;
+
+    float u[3][2][4];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = q * 64 + lane;          // float4 index inside the channel's 512 pixels
+            const int seg = e >> 2, qq = e & 3;   // seg = p0*16 + p1
+            const int p0 = seg >> 4, p1 = seg & 15;
+            const float* src = cb + (((size_t)c * T + (tt * 2 + p0)) * H + (th * 16 + p1)) * W + tw * 16 + qq * 4;
+            const f32x4 v = *(const f32x4*)src;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[c][q][k] = v[k] * c_std[c] + c_mean[c];
+        }
+    }
+    if (normalize) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) s += u[c][q][k];
+            const float mu = wave_sum(s) * (1.0f / 512.0f);
+            float ss = 0.f;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float d = u[c][q][k] - mu;
+                    ss += d * d;
+                }
+            const float var = wave_sum(ss) * (1.0f / 511.0f);
+            const float inv = 1.0f / (sqrtf(var) + 1e-6f);
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[c][q][k] = (u[c][q][k] - mu) * inv;
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = q * 64 + lane;
+        const bf16_t* pp = pred + (size_t)row * ldp + e * 12;
+        u32x2 w[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[i] = *(const u32x2*)(pp + 4 * i);
+        float pv[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            pv[4 * i + 0] = bf16lo_to_f32(w[i][0]);
+            pv[4 * i + 1] = bf16hi_to_f32(w[i][0]);
+            pv[4 * i + 2] = bf16lo_to_f32(w[i][1]);
+            pv[4 * i + 3] = bf16hi_to_f32(w[i][1]);
+        }
+        float d[12];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float t = u[c][q][k];
+                const float df = pv[k * 3 + c] - t;
+                d[k * 3 + c] = df;
+                acc += df * df;
+                if (target_out) target_out[(size_t)row * 1536 + e * 12 + k * 3 + c] = t;
+            }
+        if (dpred) {
+            bf16_t* dp = dpred + (size_t)row * lddp + e * 12;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                u32x2 o = {pack_bf16x2(d[4 * i] * gs, d[4 * i + 1] * gs), pack_bf16x2(d[4 * i + 2] * gs, d[4 * i + 3] * gs)};
+                *(u32x2*)(dp + 4 * i) = o;
+            }
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) row_loss[row] = acc;
+}
+
+// deterministic final reduction in double: loss = sum(row_loss) / numel
+__global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int rows, double inv_numel,
+                                                           float* __restrict__ loss) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < rows; i += 1024) s += (double)row_loss[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        loss[0] = (float)(t * inv_numel);
+    }
+}
+
+}  // namespace
+
+extern "C" int mofo_target_mse(const float* clips, int B, int C, int T, int H, int W, int pt, int p, const int* msk_idx,
+                               int n_msk, const void* pred, int ldp, int normalize, float grad_scale, float* row_loss,
+                               float* loss, void* dpred, int lddp, void* target_out, void* stream) {
+    if (!clips || !msk_idx || !pred || !row_loss || !loss) MOFO_FAIL(MOFO_EINVAL, "mofo_target_mse: null pointer");
+    if (C != 3 || pt != 2 || p != 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_target_mse: built for 3 channels, tubelet 2, patch 16 (got %d,%d,%d)", C, pt, p);
+    if (B <= 0 || n_msk <= 0 || T % 2 || H % 16 || W % 16 || ldp % 4 || ldp < 1536 || (dpred && (lddp % 4 || lddp < 1536)))
+        MOFO_FAIL(MOFO_EINVAL, "mofo_target_mse: bad sizes");
+    const int rows = B * n_msk;
+    const double numel = (double)rows * 1536.0;
+    const float gs = (float)(2.0 * (double)grad_scale / numel);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(target_mse_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, clips, T, H, W, msk_idx, n_msk, rows,
+                       (const bf16_t*)pred, ldp, normalize, gs, row_loss, (bf16_t*)dpred, lddp, (float*)target_out);
+    MOFO_CHECK_LAUNCH("mofo_target_mse");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, rows, 1.0 / numel, loss);
+    MOFO_CHECK_LAUNCH("mofo_target_mse(reduce)");
+    return MOFO_OK;
+}

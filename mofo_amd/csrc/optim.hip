@@ -1,0 +1,123 @@
+// Optimizer-side kernels on FLAT parameter / gradient buffers (gfx950, HBM-bound, 16-B accesses):
+//   global gradient L2 norm (utils.py:376-388 / clip_grad_norm_ at utils.py:359), fused AdamW with decoupled weight
+//   decay as torch.optim.AdamW configured by optim_factory.py:91-127, bf16 shadow refresh for the MFMA GEMMs.
+#include "common.h"
+#include "../../include/mofo_hip.h"
+#include <math.h>
+
+namespace {
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, long long n4, float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)g)[i];
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(1024) void norm_final_kernel(const float* __restrict__ partial, int n, float* __restrict__ out) {
+    __shared__ double red[16];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) s += (double)partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += red[i];
+        out[0] = (float)sqrt(t);
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, bf16_t* __restrict__ pb, long long n4,
+                                                    const uint8_t* __restrict__ chunk_group, float lr0, float wd0, float lr1,
+                                                    float wd1, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
+                                                    const float* __restrict__ grad_norm, float max_norm, float grad_mult) {
+    float gm = grad_mult;
+    if (max_norm > 0.f && grad_norm) {
+        const float coef = max_norm / (grad_norm[0] * grad_mult + 1e-6f);
+        gm *= fminf(coef, 1.0f);
+    }
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 pv = ((f32x4*)p)[i];
+        const f32x4 gv = ((const f32x4*)g)[i] * gm;
+        f32x4 mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        const bool g1 = chunk_group[i >> 8] != 0;
+        const float lr = g1 ? lr1 : lr0;
+        const float decay = 1.0f - lr * (g1 ? wd1 : wd0);
+        const float step_size = lr * inv_bc1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            mv[e] = b1 * mv[e] + (1.0f - b1) * gv[e];
+            vv[e] = b2 * vv[e] + (1.0f - b2) * gv[e] * gv[e];
+            const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
+            pv[e] = pv[e] * decay - step_size * (mv[e] / denom);
+        }
+        ((f32x4*)p)[i] = pv;
+        ((f32x4*)m)[i] = mv;
+        ((f32x4*)v)[i] = vv;
+        if (pb) {
+            u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
+            ((u32x2*)pb)[i] = pk;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const f32x4 v = ((const f32x4*)src)[i];
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        ((u32x2*)dst)[i] = pk;
+    }
+}
+
+int stream_blocks(long long n4) {
+    long long b = (n4 + 255) / 256;
+    return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
+}
+
+}  // namespace
+
+extern "C" int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, void* stream) {
+    if (!g || !partial || !out_norm) MOFO_FAIL(MOFO_EINVAL, "mofo_sumsq: null pointer");
+    if (n <= 0 || n % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_sumsq: n must be a positive multiple of 4");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(SUMSQ_BLOCKS), dim3(256), 0, s, g, n / 4, partial);
+    MOFO_CHECK_LAUNCH("mofo_sumsq");
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, SUMSQ_BLOCKS, out_norm);
+    MOFO_CHECK_LAUNCH("mofo_sumsq(final)");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                          float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                          const float* grad_norm, float max_norm, float grad_mult, void* stream) {
+    if (!p || !g || !m || !v || !chunk_group) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: null pointer");
+    if (n <= 0 || n % 1024) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_adamw: n must be a positive multiple of 1024");
+    if (step < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: step starts at 1");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    const float inv_bc1 = (float)(1.0 / bc1);
+    const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+    hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
+                       chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult);
+    MOFO_CHECK_LAUNCH("mofo_adamw");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_cast_bf16(const float* src, void* dst, long long n, void* stream) {
+    if (!src || !dst) MOFO_FAIL(MOFO_EINVAL, "mofo_cast_bf16: null pointer");
+    if (n <= 0 || n % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_cast_bf16: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(cast_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
+    MOFO_CHECK_LAUNCH("mofo_cast_bf16");
+    return MOFO_OK;
+}

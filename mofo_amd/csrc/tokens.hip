@@ -1,0 +1,205 @@
+// Token plumbing kernels (all HBM-bound, integer/byte + copy work; gfx950):
+//   mask -> ascending index lists, tubelet gather of visible patches, decoder input assembly and its backward,
+//   column sums (bias gradients).
+#include "common.h"
+#include "../../include/mofo_hip.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------- mask -> indices
+// one 256-thread block per clip; thread t owns elements [t*E, t*E+E); block-wide exclusive scan of visible counts.
+__global__ __launch_bounds__(256) void mask_idx_kernel(const uint8_t* __restrict__ mask, int N, int n_vis,
+                                                       int* __restrict__ vis_idx, int* __restrict__ msk_idx,
+                                                       int* __restrict__ status) {
+    __shared__ int wsum[4];
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int E = (N + 255) / 256;
+    const int beg = t * E, end = min(N, beg + E);
+    const uint8_t* m = mask + (size_t)b * N;
+    int cnt = 0;
+    for (int i = beg; i < end; ++i) cnt += (m[i] == 0);
+    int inc = cnt;  // inclusive scan inside the wave
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+    const int total = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (t == 0 && total != n_vis) atomicOr(status, 1);
+    int v = base + inc - cnt;               // visible tokens before `beg`
+    int k = (beg < N ? beg : N) - v;        // masked tokens before `beg`
+    const int n_msk = N - n_vis;
+    int* vo = vis_idx + (size_t)b * n_vis;
+    int* mo = msk_idx + (size_t)b * n_msk;
+    for (int i = beg; i < end; ++i) {
+        if (m[i] == 0) {
+            if (v < n_vis) vo[v] = i;
+            ++v;
+        } else {
+            if (k < n_msk) mo[k] = i;
+            ++k;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- tubelet gather
+// one wave per token row; lane e handles float4 #e of the row: row layout (c, p0, p1, p2) so that float4 #e is 16 B
+// of one 16-pixel image row segment (64 B contiguous in the clip).
+__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ clips, int C, int T, int H, int W,
+                                                           int pt, int p, const int* __restrict__ tok_idx, int n_tok,
+                                                           int rows, bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / n_tok;
+    const int tok = tok_idx[row];
+    const int gw = W / p, gh = H / p;
+    const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
+    const int q4 = p >> 2;            // float4 per segment
+    const int n4 = C * pt * p * q4;   // float4 per row
+    const float* cb = clips + (size_t)b * C * T * H * W;
+    bf16_t* orow = out + (size_t)row * ldo;
+    for (int e = lane; e < n4; e += 64) {
+        const int seg = e / q4, qq = e - seg * q4;
+        const int c = seg / (pt * p), rem = seg - c * (pt * p);
+        const int p0 = rem / p, p1 = rem - p0 * p;
+        const float* src = cb + (((size_t)c * T + (tt * pt + p0)) * H + (th * p + p1)) * W + tw * p + qq * 4;
+        const f32x4 v = *(const f32x4*)src;
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(orow + e * 4) = pk;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- decoder assembly
+__global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict__ mask_token, const float* __restrict__ pos,
+                                                        int ldpos, const int* __restrict__ msk_idx, int N, int n_vis, int D,
+                                                        int rows, float* __restrict__ x_full) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int n_msk = N - n_vis;
+    const int b = row / n_msk, j = row - b * n_msk;
+    const float* pr = pos + (size_t)msk_idx[row] * ldpos;
+    float* dst = x_full + ((size_t)b * N + n_vis + j) * D;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *(const f32x4*)(mask_token + c) + *(const f32x4*)(pr + c);
+        *(f32x4*)(dst + c) = v;
+    }
+}
+
+// blockDim = D/4 rounded up to 64; each block handles RB consecutive rows of dx_full [B*N, D]
+constexpr int RB = 32;
+__global__ void assemble_bwd_kernel(const float* __restrict__ dx, int N, int n_vis, int D, int rows,
+                                    bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {
+    const int c = threadIdx.x * 4;
+    if (c >= D) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int r0 = blockIdx.x * RB;
+    for (int r = r0; r < min(rows, r0 + RB); ++r) {
+        const int b = r / N, j = r - b * N;
+        const f32x4 v = *(const f32x4*)(dx + (size_t)r * D + c);
+        if (j < n_vis) {
+            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            *(u32x2*)(d_e2d + ((size_t)b * n_vis + j) * D + c) = pk;
+        } else {
+            acc += v;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) atomicAdd(d_mask_token + c + e, acc[e]);
+}
+
+// ---------------------------------------------------------------------------------------------- column sums
+// block = 256 threads = 32 row lanes x 8 column groups of 8 bf16 (16 B): 64 columns x `rows_per_block` rows per block.
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ X, int ldx, int M, int N,
+                                                          int rows_per_block, float* __restrict__ out) {
+    __shared__ float red[32][65];
+    const int cg = threadIdx.x & 7, rl = threadIdx.x >> 3;
+    const int c0 = blockIdx.x * 64 + cg * 8;
+    const int rbeg = blockIdx.y * rows_per_block, rend = min(M, rbeg + rows_per_block);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (c0 < N) {
+        for (int r = rbeg + rl; r < rend; r += 32) {
+            const u32x4 v = *(const u32x4*)(X + (size_t)r * ldx + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[2 * e] += bf16lo_to_f32(v[e]);
+                acc[2 * e + 1] += bf16hi_to_f32(v[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[rl][cg * 8 + e] = acc[e];
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+        const int c = blockIdx.x * 64 + threadIdx.x;
+        if (c < N) atomicAdd(out + c, s);
+    }
+}
+
+}  // namespace
+
+extern "C" int mofo_mask_to_indices(const uint8_t* mask, int B, int N, int n_vis, int* vis_idx, int* msk_idx, int* status,
+                                    void* stream) {
+    if (!mask || !vis_idx || !msk_idx || !status) MOFO_FAIL(MOFO_EINVAL, "mofo_mask_to_indices: null pointer");
+    if (B <= 0 || N <= 0 || n_vis <= 0 || n_vis >= N) MOFO_FAIL(MOFO_EINVAL, "mofo_mask_to_indices: bad sizes B=%d N=%d n_vis=%d", B, N, n_vis);
+    hipLaunchKernelGGL(mask_idx_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, mask, N, n_vis, vis_idx, msk_idx, status);
+    MOFO_CHECK_LAUNCH("mofo_mask_to_indices");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int pt, int p, const int* tok_idx,
+                                 int n_tok, void* out, int ldo, void* stream) {
+    if (!clips || !tok_idx || !out) MOFO_FAIL(MOFO_EINVAL, "mofo_patch_gather: null pointer");
+    if (B <= 0 || C <= 0 || T <= 0 || H <= 0 || W <= 0 || pt <= 0 || p <= 0 || n_tok <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_patch_gather: bad sizes");
+    if (p % 4 || W % 4 || T % pt || H % p || W % p || ldo % 4 || ldo < C * pt * p * p)
+        MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_patch_gather: patch %d / tubelet %d do not tile %dx%dx%d or ldo too small", p, pt, T, H, W);
+    const int rows = B * n_tok;
+    hipLaunchKernelGGL(patch_gather_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, clips, C, T, H, W, pt, p,
+                       tok_idx, n_tok, rows, (bf16_t*)out, ldo);
+    MOFO_CHECK_LAUNCH("mofo_patch_gather");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx, int B, int N,
+                                     int n_vis, int D, float* x_full, void* stream) {
+    if (!mask_token || !pos || !msk_idx || !x_full) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: null pointer");
+    if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || ldpos % 4) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: bad sizes");
+    const int rows = B * (N - n_vis);
+    hipLaunchKernelGGL(fill_mask_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
+                       msk_idx, N, n_vis, D, rows, x_full);
+    MOFO_CHECK_LAUNCH("mofo_fill_mask_tokens");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_assemble_bwd(const float* dx_full, int B, int N, int n_vis, int D, void* d_e2d, float* d_mask_token,
+                                 void* stream) {
+    if (!dx_full || !d_e2d || !d_mask_token) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: null pointer");
+    if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || D > 4096) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: bad sizes");
+    const int rows = B * N;
+    const int threads = ceil_div(D / 4, 64) * 64;
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(ceil_div(rows, RB)), dim3(threads), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
+                       rows, (bf16_t*)d_e2d, d_mask_token);
+    MOFO_CHECK_LAUNCH("mofo_assemble_bwd");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* stream) {
+    if (!X || !out) MOFO_FAIL(MOFO_EINVAL, "mofo_colsum_bf16: null pointer");
+    if (M <= 0 || N <= 0 || N % 8 || ldx % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_colsum_bf16: N and ldx must be multiples of 8");
+    const int cb = ceil_div(N, 64);
+    int rsplit = ceil_div(1024, cb);
+    int rpb = ceil_div(ceil_div(M, rsplit), 32) * 32;
+    if (rpb < 256) rpb = 256;
+    rsplit = ceil_div(M, rpb);
+    hipLaunchKernelGGL(colsum_bf16_kernel, dim3(cb, rsplit), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)X, ldx, M, N, rpb, out);
+    MOFO_CHECK_LAUNCH("mofo_colsum_bf16");
+    return MOFO_OK;
+}
