@@ -1,0 +1,251 @@
+"""Thin, checked wrappers: torch tensors in, C-ABI calls on torch's current HIP stream out.
+
+PyTorch is plumbing here (device memory + streams); every computation is a kernel in libmofo_hip.so.
+These wrappers validate device / dtype / layout so that a wrong shape raises here instead of faulting on the GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (EPI_BF16, EPI_BIAS_GELU, EPI_DGELU_BF16, EPI_F32, EPI_POS_F32, EPI_RESID_F32, GEMM_NN, GEMM_NT,
+                   GEMM_TN, GemmArgs)
+
+BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _chk(t, dtype, name, dims=None):
+    if t is None:
+        raise ValueError(f"{name} is None")
+    if not t.is_cuda:
+        raise ValueError(f"{name} must be on the GPU (mofo_amd has no CPU path)")
+    if t.dtype != dtype:
+        raise TypeError(f"{name} must be {dtype}, got {t.dtype}")
+    if dims is not None and t.dim() != dims:
+        raise ValueError(f"{name} must have {dims} dims, got {tuple(t.shape)}")
+    if t.dim() >= 1 and t.stride(-1) != 1 and t.numel() > 0:
+        raise ValueError(f"{name} must be contiguous in its last dim")
+    return t
+
+
+def _ld(t):
+    """leading dimension (elements) of a 2-D row-major view"""
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[1], t.stride(0))
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def gemm(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
+         row_off=0, splits=1, accumulate=False):
+    """C = epilogue(A (op) B).  A, B bf16 2-D; see include/mofo_hip.h for op / epilogue semantics."""
+    _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
+    if op == GEMM_NT:
+        M, K = A.shape
+        N, K2 = B.shape
+    elif op == GEMM_NN:
+        M, K = A.shape
+        K2, N = B.shape
+    elif op == GEMM_TN:
+        K, M = A.shape
+        K2, N = B.shape
+    else:
+        raise ValueError("bad op")
+    if K != K2:
+        raise ValueError(f"reduction mismatch: {tuple(A.shape)} vs {tuple(B.shape)} for op {op}")
+    out_dtype = F32 if epi in (EPI_RESID_F32, EPI_POS_F32, EPI_F32) else BF16
+    _chk(C_, out_dtype, "C", 2)
+    if epi != EPI_POS_F32 and tuple(C_.shape) != (M, N):
+        raise ValueError(f"C must be {(M, N)}, got {tuple(C_.shape)}")
+    if epi == EPI_POS_F32:
+        _chk(pos, F32, "pos", 2), _chk(row_idx, I32, "row_idx")
+        if row_idx.numel() != M or pos.shape[1] != N or C_.shape[1] != N or rows_in <= 0:
+            raise ValueError("POS_F32: row_idx must have M entries, pos/C must have N columns")
+        if (M // rows_in) * rows_out + row_off > C_.shape[0] or M % rows_in:
+            raise ValueError("POS_F32: row map exceeds C")
+    if bias is not None:
+        _chk(bias, F32, "bias", 1)
+        if bias.numel() != N:
+            raise ValueError("bias must have N entries")
+    if epi == EPI_BIAS_GELU:
+        _chk(C2, BF16, "C2", 2)
+        if tuple(C2.shape) != (M, N):
+            raise ValueError("C2 shape")
+    if epi == EPI_RESID_F32:
+        _chk(resid, F32, "resid", 2)
+        if tuple(resid.shape) != (M, N):
+            raise ValueError("resid shape")
+    if epi == EPI_DGELU_BF16:
+        _chk(aux, BF16, "aux", 2)
+        if tuple(aux.shape) != (M, N):
+            raise ValueError("aux shape")
+    a = GemmArgs(op=op, epilogue=epi, M=M, N=N, K=K, A=_p(A), lda=_ld(A), B=_p(B), ldb=_ld(B), C=_p(C_), ldc=_ld(C_),
+                 C2=_p(C2), ldc2=_ld(C2) if C2 is not None else 0, bias=_p(bias), resid=_p(resid),
+                 ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
+                 pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
+                 rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0)
+    _lib.check(_lib.load().mofo_gemm(C.byref(a), _stream()), "mofo_gemm")
+    return C_
+
+
+def colsum_bf16(X, out):
+    _chk(X, BF16, "X", 2), _chk(out, F32, "out", 1)
+    if out.numel() != X.shape[1]:
+        raise ValueError("out must have N entries")
+    _lib.check(_lib.load().mofo_colsum_bf16(_p(X), _ld(X), X.shape[0], X.shape[1], _p(out), _stream()), "mofo_colsum_bf16")
+    return out
+
+
+def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=None, row_off=0):
+    _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(y, BF16, "y", 2), _chk(mean, F32, "mean", 1), _chk(rstd, F32, "rstd", 1)
+    D = x.shape[1]
+    M = y.shape[0] if M is None else M
+    rows_in = M if rows_in is None else rows_in
+    rows_out = rows_in if rows_out is None else rows_out
+    if w.numel() != D or b.numel() != D or y.shape[1] != D or mean.numel() < M or rstd.numel() < M or y.shape[0] < M:
+        raise ValueError("layernorm_fwd: shape mismatch")
+    if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
+        raise ValueError("layernorm_fwd: row map exceeds x")
+    _lib.check(_lib.load().mofo_layernorm_fwd(_p(x), _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off, _p(y), _ld(y),
+                                              _p(mean), _p(rstd), _stream()), "mofo_layernorm_fwd")
+    return y
+
+
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0):
+    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(dx, F32, "dx", 2), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
+    D = x.shape[1]
+    M = dy.shape[0] if M is None else M
+    rows_in = M if rows_in is None else rows_in
+    rows_out = rows_in if rows_out is None else rows_out
+    if dres is not None:
+        _chk(dres, F32, "dres", 2)
+        if dres.shape != x.shape:
+            raise ValueError("dres shape")
+    if dxb is not None:
+        _chk(dxb, BF16, "dxb", 2)
+        if dxb.shape != x.shape:
+            raise ValueError("dxb shape")
+    if dx.shape != x.shape or dy.shape[1] != D or dw.numel() != D or db.numel() != D or dy.shape[0] < M:
+        raise ValueError("layernorm_bwd: shape mismatch")
+    if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
+        raise ValueError("layernorm_bwd: row map exceeds x")
+    _lib.check(_lib.load().mofo_layernorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres),
+                                              _ld(dres) if dres is not None else 0, M, D, rows_in, rows_out, row_off,
+                                              _p(dx), _ld(dx), _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
+                                              _stream()), "mofo_layernorm_bwd")
+
+
+def attention_fwd(qkv, B, N, H, scale, out, lse2):
+    _chk(qkv, BF16, "qkv", 2), _chk(out, BF16, "out", 2), _chk(lse2, F32, "lse2")
+    if qkv.shape != (B * N, 3 * H * 64) or out.shape != (B * N, H * 64) or lse2.numel() != B * H * N:
+        raise ValueError("attention_fwd: shape mismatch")
+    _lib.check(_lib.load().mofo_attention_fwd(_p(qkv), _ld(qkv), B, N, H, scale, _p(out), _ld(out), _p(lse2), _stream()),
+               "mofo_attention_fwd")
+    return out
+
+
+def attention_bwd(qkv, out, dout, lse2, B, N, H, scale, dqkv, delta):
+    _chk(qkv, BF16, "qkv", 2), _chk(out, BF16, "out", 2), _chk(dout, BF16, "dout", 2), _chk(dqkv, BF16, "dqkv", 2)
+    _chk(lse2, F32, "lse2"), _chk(delta, F32, "delta")
+    if (qkv.shape != (B * N, 3 * H * 64) or dqkv.shape != qkv.shape or out.shape != (B * N, H * 64) or dout.shape != out.shape
+            or lse2.numel() != B * H * N or delta.numel() != B * H * N):
+        raise ValueError("attention_bwd: shape mismatch")
+    _lib.check(_lib.load().mofo_attention_bwd(_p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout), _p(lse2), B, N, H, scale,
+                                              _p(dqkv), _ld(dqkv), _p(delta), _stream()), "mofo_attention_bwd")
+    return dqkv
+
+
+def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
+    _chk(mask_u8, U8, "mask", 2), _chk(vis_idx, I32, "vis_idx", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(status, I32, "status")
+    B, N = mask_u8.shape
+    if not mask_u8.is_contiguous() or vis_idx.shape != (B, n_vis) or msk_idx.shape != (B, N - n_vis):
+        raise ValueError("mask_to_indices: shape mismatch")
+    _lib.check(_lib.load().mofo_mask_to_indices(_p(mask_u8), B, N, n_vis, _p(vis_idx), _p(msk_idx), _p(status), _stream()),
+               "mofo_mask_to_indices")
+
+
+def patch_gather(clips, pt, p, tok_idx, out):
+    _chk(clips, F32, "clips", 5), _chk(tok_idx, I32, "tok_idx", 2), _chk(out, BF16, "out", 2)
+    B, Cc, T, H, W = clips.shape
+    if not clips.is_contiguous() or not tok_idx.is_contiguous() or tok_idx.shape[0] != B:
+        raise ValueError("patch_gather: clips / tok_idx must be contiguous with matching batch")
+    n_tok = tok_idx.shape[1]
+    if out.shape != (B * n_tok, Cc * pt * p * p):
+        raise ValueError("patch_gather: out shape")
+    _lib.check(_lib.load().mofo_patch_gather(_p(clips), B, Cc, T, H, W, pt, p, _p(tok_idx), n_tok, _p(out), _ld(out), _stream()),
+               "mofo_patch_gather")
+    return out
+
+
+def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
+    _chk(mask_token, F32, "mask_token"), _chk(pos, F32, "pos", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(x_full, F32, "x_full", 3)
+    B, N, D = x_full.shape
+    if not x_full.is_contiguous() or mask_token.numel() != D or pos.shape[1] != D or msk_idx.shape != (B, N - n_vis) or pos.shape[0] < N:
+        raise ValueError("fill_mask_tokens: shape mismatch")
+    _lib.check(_lib.load().mofo_fill_mask_tokens(_p(mask_token), _p(pos), _ld(pos), _p(msk_idx), B, N, n_vis, D, _p(x_full), _stream()),
+               "mofo_fill_mask_tokens")
+
+
+def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
+    _chk(dx_full, F32, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2), _chk(d_mask_token, F32, "d_mask_token")
+    B, N, D = dx_full.shape
+    if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or d_mask_token.numel() != D:
+        raise ValueError("assemble_bwd: shape mismatch")
+    _lib.check(_lib.load().mofo_assemble_bwd(_p(dx_full), B, N, n_vis, D, _p(d_e2d), _p(d_mask_token), _stream()), "mofo_assemble_bwd")
+
+
+def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, loss, dpred=None, target_out=None):
+    _chk(clips, F32, "clips", 5), _chk(msk_idx, I32, "msk_idx", 2), _chk(pred, BF16, "pred", 2), _chk(row_loss, F32, "row_loss"), _chk(loss, F32, "loss")
+    B, Cc, T, H, W = clips.shape
+    n_msk = msk_idx.shape[1]
+    L = Cc * pt * p * p
+    if not clips.is_contiguous() or not msk_idx.is_contiguous() or msk_idx.shape[0] != B or pred.shape != (B * n_msk, L) or row_loss.numel() < B * n_msk:
+        raise ValueError("target_mse: shape mismatch")
+    if dpred is not None:
+        _chk(dpred, BF16, "dpred", 2)
+        if dpred.shape != pred.shape:
+            raise ValueError("dpred shape")
+    if target_out is not None:
+        _chk(target_out, F32, "target_out", 2)
+        if target_out.shape != pred.shape or not target_out.is_contiguous():
+            raise ValueError("target_out shape")
+    _lib.check(_lib.load().mofo_target_mse(_p(clips), B, Cc, T, H, W, pt, p, _p(msk_idx), n_msk, _p(pred), _ld(pred),
+                                           1 if normalize else 0, grad_scale, _p(row_loss), _p(loss), _p(dpred),
+                                           _ld(dpred) if dpred is not None else 0, _p(target_out), _stream()), "mofo_target_mse")
+    return loss
+
+
+def sumsq_norm(g, partial, out_norm):
+    _chk(g, F32, "g", 1), _chk(partial, F32, "partial", 1), _chk(out_norm, F32, "out_norm")
+    if partial.numel() < 1024:
+        raise ValueError("partial must hold 1024 floats")
+    _lib.check(_lib.load().mofo_sumsq(_p(g), g.numel(), _p(partial), _p(out_norm), _stream()), "mofo_sumsq")
+    return out_norm
+
+
+def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0):
+    for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
+        _chk(t, F32, n, 1)
+    _chk(chunk_group, U8, "chunk_group", 1)
+    n = p.numel()
+    if g.numel() != n or m.numel() != n or v.numel() != n or chunk_group.numel() * 1024 != n:
+        raise ValueError("adamw: flat buffers must share one length = 1024 * len(chunk_group)")
+    if p_bf16 is not None:
+        _chk(p_bf16, BF16, "p_bf16", 1)
+        if p_bf16.numel() != n:
+            raise ValueError("p_bf16 length")
+    _lib.check(_lib.load().mofo_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group), lr0, wd0, lr1, wd1, beta1, beta2,
+                                      eps, step, _p(grad_norm), max_norm, grad_mult, _stream()), "mofo_adamw")
+
+
+def cast_bf16(src, dst):
+    _chk(src, F32, "src", 1), _chk(dst, BF16, "dst", 1)
+    if src.numel() != dst.numel():
+        raise ValueError("cast_bf16: length mismatch")
+    _lib.check(_lib.load().mofo_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "mofo_cast_bf16")
+    return dst

@@ -1,0 +1,401 @@
+"""Per-kernel parity on a real MI355X: every C-ABI entry against a plain fp32 torch restatement of the same op
+(and the oracle where the op is a reference function).  Inputs are asymmetric random data so that a transposed
+fragment map or a swapped operand cannot hide."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from mofo_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def _rand(shape, dev, seed, scale=1.0, dtype=BF16):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def _rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (320, 2304, 768), (77, 192, 128), (16, 64, 64), (640, 768, 3072), (1000, 1536, 384)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_nt_epilogues(dev, M, N, K):
+    from mofo_amd import ops
+    A = _rand((M, K), dev, 1)
+    B = _rand((N, K), dev, 2, 0.05)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    ref = A.float() @ B.float().t()
+    # plain bf16 store, no bias
+    Cb = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, B, Cb)
+    assert _rel(Cb, ref) < 6e-3
+    # exact-value check on a few entries (catches permuted rows/cols that a norm might not)
+    idx = torch.randint(0, M * N, (64,), generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(Cb.flatten()[idx].float(), ref.flatten()[idx], rtol=2e-2, atol=2e-2)
+    # bias
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, B, Cb, bias=bias)
+    assert _rel(Cb, ref + bias) < 6e-3
+    # bias + gelu (two outputs)
+    C2 = torch.empty_like(Cb)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, A, B, Cb, C2=C2, bias=bias)
+    h = ref + bias
+    assert _rel(Cb, h) < 6e-3
+    assert _rel(C2, torch.nn.functional.gelu(h)) < 8e-3
+    # residual, fp32 out
+    R = _rand((M, N), dev, 4, 1.0, F32)
+    Cf = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, B, Cf, bias=bias, resid=R)
+    assert _rel(Cf, h + R) < 1e-5 + 1e-6 * math.sqrt(K)
+    # f32 plain, split-K with atomics, accumulate
+    ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf)
+    assert _rel(Cf, ref) < 1e-5
+    if K >= 128:
+        Cf.zero_()
+        ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf, splits=2)
+        assert _rel(Cf, ref) < 1e-5
+        ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf, accumulate=True)
+        assert _rel(Cf, 2 * ref) < 1e-5
+
+
+def test_gemm_nt_pos_rowmap(dev):
+    from mofo_amd import ops
+    Bc, nv, Ntok, K, N = 3, 20, 50, 128, 192
+    M = Bc * nv
+    A = _rand((M, K), dev, 1)
+    W = _rand((N, K), dev, 2, 0.05)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    pos = _rand((Ntok, N), dev, 4, 1.0, F32)
+    idx = torch.stack([torch.randperm(Ntok, generator=torch.Generator().manual_seed(b))[:nv].sort().values for b in range(Bc)]).int().to(dev)
+    out = torch.full((Bc * Ntok, N), -7.0, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, A, W, out, bias=bias, pos=pos, row_idx=idx.flatten(), rows_in=nv, rows_out=Ntok, row_off=0)
+    ref = (A.float() @ W.float().t() + bias + pos[idx.flatten().long()]).view(Bc, nv, N)
+    got = out.view(Bc, Ntok, N)
+    assert _rel(got[:, :nv], ref) < 1e-5
+    assert torch.all(got[:, nv:] == -7.0)      # rows outside the map untouched
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 768, 2304), (77, 128, 192), (640, 3072, 768), (50, 64, 256)])
+def test_gemm_nn_dgrad(dev, M, N, K):
+    from mofo_amd import ops
+    A = _rand((M, K), dev, 1)            # dY [M, Nf]
+    W = _rand((K, N), dev, 2, 0.05)      # W  [Nf, Kf] read reduction-strided
+    ref = A.float() @ W.float()
+    Cb = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NN, ops.EPI_BF16, A, W, Cb)
+    assert _rel(Cb, ref) < 6e-3
+    idx = torch.randint(0, M * N, (64,), generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(Cb.flatten()[idx].float(), ref.flatten()[idx], rtol=2e-2, atol=2e-2)
+    hpre = _rand((M, N), dev, 6)
+    ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, A, W, Cb, aux=hpre)
+    x = hpre.float().requires_grad_(True)
+    torch.nn.functional.gelu(x).backward(ref)
+    assert _rel(Cb, x.grad) < 8e-3
+
+
+@pytest.mark.parametrize("R,P,Q", [(64, 128, 128), (320, 2304, 768), (320, 768, 1536), (100, 192, 64), (1568, 384, 1536), (48, 64, 128)])
+def test_gemm_tn_wgrad(dev, R, P, Q):
+    from mofo_amd import ops
+    dY = _rand((R, P), dev, 1)
+    X = _rand((R, Q), dev, 2)
+    ref = dY.float().t() @ X.float()
+    C = torch.zeros(P, Q, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, C)
+    assert _rel(C, ref) < 1e-5
+    idx = torch.randint(0, P * Q, (64,), generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(C.flatten()[idx], ref.flatten()[idx], rtol=1e-3, atol=1e-3)
+    C.zero_()
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, C, splits=3, accumulate=True)
+    assert _rel(C, ref) < 1e-5
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, C, splits=2, accumulate=True)
+    assert _rel(C, 2 * ref) < 1e-5
+
+
+def test_gemm_rejects_bad_shapes(dev):
+    from mofo_amd import ops
+    A = _rand((64, 96), dev, 1)
+    B = _rand((64, 96), dev, 2)
+    C = torch.empty(64, 64, dtype=BF16, device=dev)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, B, C)
+    with pytest.raises(TypeError):
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.float(), B, C)
+    with pytest.raises(ValueError):
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.cpu(), B, C)
+
+
+def test_colsum(dev):
+    from mofo_amd import ops
+    for M, N in [(320, 768), (3136, 1536), (37, 64)]:
+        X = _rand((M, N), dev, 1)
+        out = torch.zeros(N, dtype=F32, device=dev)
+        ops.colsum_bf16(X, out)
+        assert _rel(out, X.float().sum(0)) < 1e-5
+    # strided view (the q / v thirds of a dqkv buffer)
+    X = _rand((200, 384), dev, 2)
+    out = torch.zeros(128, dtype=F32, device=dev)
+    ops.colsum_bf16(X[:, 256:], out)
+    assert _rel(out, X[:, 256:].float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("M,D", [(320, 768), (3136, 384), (16, 128), (64, 64), (7, 1024), (33, 512)])
+def test_layernorm_fwd_bwd(dev, M, D):
+    from mofo_amd import ops
+    x = _rand((M, D), dev, 1, 2.0, F32) + 0.5
+    w = _rand((D,), dev, 2, 0.3, F32) + 1.0
+    b = _rand((D,), dev, 3, 0.3, F32)
+    y = torch.empty(M, D, dtype=BF16, device=dev)
+    mean = torch.empty(M, dtype=F32, device=dev)
+    rstd = torch.empty(M, dtype=F32, device=dev)
+    ops.layernorm_fwd(x, w, b, 1e-6, y, mean, rstd)
+    xr = x.clone().requires_grad_(True)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xr, (D,), wr, br, 1e-6)
+    assert _rel(y, yr) < 4e-3
+    assert torch.allclose(mean, x.mean(1), atol=1e-5, rtol=1e-5)
+    assert torch.allclose(rstd, 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-6), rtol=1e-4)
+    dy = _rand((M, D), dev, 4)
+    dres = _rand((M, D), dev, 5, 1.0, F32)
+    yr.backward(dy.float())
+    dx = torch.empty(M, D, dtype=F32, device=dev)
+    dxb = torch.empty(M, D, dtype=BF16, device=dev)
+    dw = torch.zeros(D, dtype=F32, device=dev)
+    db = torch.zeros(D, dtype=F32, device=dev)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db)
+    assert _rel(dx, xr.grad + dres) < 1e-5
+    assert _rel(dxb, xr.grad + dres) < 4e-3
+    assert _rel(dw, wr.grad) < 1e-4
+    assert _rel(db, br.grad) < 1e-4
+    # no residual, no bf16 copy
+    dw.zero_(), db.zero_()
+    ops.layernorm_bwd(dy, x, w, mean, rstd, None, dx, None, dw, db)
+    assert _rel(dx, xr.grad) < 1e-5
+
+
+def test_layernorm_rowmap(dev):
+    """decoder final norm: only the last n_msk rows of every clip (modeling_pretrain.py:157)."""
+    from mofo_amd import ops
+    Bc, N, nv, D = 3, 32, 8, 128
+    nm = N - nv
+    x = _rand((Bc * N, D), dev, 1, 1.0, F32)
+    w = _rand((D,), dev, 2, 0.3, F32) + 1.0
+    b = _rand((D,), dev, 3, 0.3, F32)
+    y = torch.empty(Bc * nm, D, dtype=BF16, device=dev)
+    mean = torch.empty(Bc * nm, dtype=F32, device=dev)
+    rstd = torch.empty_like(mean)
+    ops.layernorm_fwd(x, w, b, 1e-6, y, mean, rstd, rows_in=nm, rows_out=N, row_off=nv)
+    xs = x.view(Bc, N, D)[:, nv:].reshape(-1, D).clone().requires_grad_(True)
+    yr = torch.nn.functional.layer_norm(xs, (D,), w, b, 1e-6)
+    assert _rel(y, yr) < 4e-3
+    dy = _rand((Bc * nm, D), dev, 4)
+    yr.backward(dy.float())
+    dx = torch.zeros(Bc * N, D, dtype=F32, device=dev)
+    dxb = torch.zeros(Bc * N, D, dtype=BF16, device=dev)
+    dw = torch.zeros(D, dtype=F32, device=dev)
+    db = torch.zeros(D, dtype=F32, device=dev)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, None, dx, dxb, dw, db, rows_in=nm, rows_out=N, row_off=nv)
+    got = dx.view(Bc, N, D)
+    assert torch.all(got[:, :nv] == 0)
+    assert _rel(got[:, nv:].reshape(-1, D), xs.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(qkv, B, N, H, scale):
+    q, k, v = qkv.float().view(B, N, 3, H, 64).permute(2, 0, 3, 1, 4)
+    s = (q * scale) @ k.transpose(-2, -1)
+    p = s.softmax(-1)
+    return (p @ v).transpose(1, 2).reshape(B * N, H * 64), s
+
+
+@pytest.mark.parametrize("B,N,H", [(2, 160, 12), (1, 1568, 6), (3, 8, 2), (2, 32, 1), (2, 50, 3), (1, 224, 2), (1, 320, 4)])
+def test_attention_fwd_bwd(dev, B, N, H):
+    from mofo_amd import ops
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _rand((B * N, 3 * D), dev, 1, 1.5)
+    out = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
+    x = qkv.float().requires_grad_(True)
+    ref, s = _attn_ref(x, B, N, H, scale)
+    assert _rel(out, ref) < 8e-3
+    lse_ref = torch.logsumexp(s, -1) * 1.4426950408889634     # [B,H,N] in log2 units
+    assert torch.allclose(lse2.view(B, H, N), lse_ref.detach(), atol=2e-2, rtol=1e-3)
+    dout = _rand((B * N, D), dev, 2)
+    ref.backward(dout.float())
+    dqkv = torch.empty_like(qkv)
+    delta = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_bwd(qkv, out, dout, lse2, B, N, H, scale, dqkv, delta)
+    g = x.grad
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(dqkv[:, sl], g[:, sl]) < 2e-2, name
+
+
+def test_attention_spiky_softmax(dev):
+    """one key dominates late in the sequence -> the online-softmax rescale branch must fire and be right."""
+    from mofo_amd import ops
+    B, N, H = 1, 160, 1
+    qkv = _rand((B * N, 192), dev, 3, 0.5)
+    qkv[100, 64:128] = qkv[7, 0:64] * 40.0   # key 100 aligned with query 7
+    out = torch.empty(B * N, 64, dtype=BF16, device=dev)
+    lse2 = torch.empty(N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, 0.125, out, lse2)
+    ref, _ = _attn_ref(qkv, B, N, H, 0.125)
+    assert _rel(out, ref) < 8e-3
+    assert torch.allclose(out[7].float(), ref[7], atol=3e-2, rtol=3e-2)
+
+
+# ------------------------------------------------------------------------------------------------ token plumbing
+def test_mask_to_indices(dev):
+    from mofo_amd import ops
+    from oracle import pretrain_oracle as O
+    np.random.seed(3)
+    masks = np.stack([O.tube_mask((8, 14, 14), 0.9) for _ in range(5)]).astype(np.uint8)
+    m = torch.from_numpy(masks).to(dev)
+    vis = torch.empty(5, 160, dtype=torch.int32, device=dev)
+    msk = torch.empty(5, 1408, dtype=torch.int32, device=dev)
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.mask_to_indices(m, 160, vis, msk, st)
+    for b in range(5):
+        assert vis[b].cpu().tolist() == np.nonzero(masks[b] == 0)[0].tolist()
+        assert msk[b].cpu().tolist() == np.nonzero(masks[b] == 1)[0].tolist()
+    assert int(st.item()) == 0
+    bad = m.clone()
+    bad[2, 0] = 1 - bad[2, 0]
+    ops.mask_to_indices(bad, 160, vis, msk, st)
+    assert int(st.item()) == 1
+    # tiny geometry (N=32 < 256 threads)
+    t = torch.tensor([[1, 0, 1, 1] * 8, [0, 1, 1, 1] * 8], dtype=torch.uint8, device=dev)
+    vis = torch.empty(2, 8, dtype=torch.int32, device=dev)
+    msk = torch.empty(2, 24, dtype=torch.int32, device=dev)
+    st.zero_()
+    ops.mask_to_indices(t, 8, vis, msk, st)
+    assert vis[0].cpu().tolist() == list(range(1, 32, 4)) and vis[1].cpu().tolist() == list(range(0, 32, 4))
+    assert int(st.item()) == 0
+
+
+@pytest.mark.parametrize("cfgname", ["TINY", "VIT_B"])
+def test_patch_gather_and_embed(dev, cfgname):
+    from mofo_amd import ops
+    from oracle import pretrain_oracle as O
+    cfg = getattr(O, cfgname)
+    Bc = 2
+    x = O.keyed_clips(Bc, cfg)
+    P = O.keyed_params(cfg, "xavier")
+    np.random.seed(1)
+    ratio = 0.75 if cfgname == "TINY" else 0.9
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, ratio) for _ in range(Bc)])).bool()
+    nv = int((~mask[0]).sum())
+    vis = torch.stack([torch.nonzero(~mask[b]).flatten() for b in range(Bc)]).int().to(dev)
+    out = torch.empty(Bc * nv, cfg.patch_dim, dtype=BF16, device=dev)
+    ops.patch_gather(x.to(dev), cfg.tubelet, cfg.patch_size, vis, out)
+    ref_rows = O.patchify_tubelets(x, cfg)[~mask].reshape(Bc * nv, -1)
+    assert torch.equal(out.cpu(), ref_rows.to(BF16))          # pure data movement + one rounding: bit exact
+    # patch-embed GEMM + bias + pos over visible tokens == reference PatchEmbed + pos + x[~mask]
+    W = P["encoder.patch_embed.proj.weight"].reshape(cfg.enc_dim, -1).to(BF16).to(dev)
+    bias = P["encoder.patch_embed.proj.bias"].to(dev)
+    pos = O.sincos_table(cfg.num_patches, cfg.enc_dim)[0].to(dev)
+    x0 = torch.empty(Bc * nv, cfg.enc_dim, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, out, W, x0, bias=bias, pos=pos, row_idx=vis.flatten(), rows_in=Bc * nv, rows_out=Bc * nv)
+    ref = (O.patch_embed(x, P, cfg) + O.sincos_table(cfg.num_patches, cfg.enc_dim))[~mask].reshape(Bc * nv, -1)
+    assert _rel(x0.cpu(), ref) < 5e-3
+
+
+def test_assemble_fwd_bwd(dev):
+    from mofo_amd import ops
+    Bc, N, nv, D = 3, 32, 8, 128
+    tok = _rand((D,), dev, 1, 0.02, F32)
+    pos = _rand((N, D), dev, 2, 1.0, F32)
+    msk = torch.stack([torch.randperm(N, generator=torch.Generator().manual_seed(b))[: N - nv].sort().values for b in range(Bc)]).int().to(dev)
+    xf = torch.full((Bc, N, D), 3.0, dtype=F32, device=dev)
+    ops.fill_mask_tokens(tok, pos, msk, nv, xf)
+    assert torch.all(xf[:, :nv] == 3.0)
+    assert torch.equal(xf[:, nv:], (tok + pos[msk.long()]))
+    dx = _rand((Bc, N, D), dev, 3, 1.0, F32)
+    de = torch.empty(Bc * nv, D, dtype=BF16, device=dev)
+    dt = torch.zeros(D, dtype=F32, device=dev)
+    ops.assemble_bwd(dx, nv, de, dt)
+    assert torch.equal(de.view(Bc, nv, D), dx[:, :nv].to(BF16))
+    assert _rel(dt, dx[:, nv:].sum((0, 1))) < 1e-5
+
+
+@pytest.mark.parametrize("cfgname,normalize", [("TINY", True), ("VIT_B", True), ("VIT_B", False)])
+def test_target_mse(dev, cfgname, normalize):
+    from mofo_amd import ops
+    from oracle import pretrain_oracle as O
+    cfg = getattr(O, cfgname)
+    Bc = 2
+    x = O.keyed_clips(Bc, cfg)
+    np.random.seed(2)
+    ratio = 0.75 if cfgname == "TINY" else 0.9
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, ratio) for _ in range(Bc)])).bool()
+    nm = int(mask[0].sum())
+    msk = torch.stack([torch.nonzero(mask[b]).flatten() for b in range(Bc)]).int().to(dev)
+    labels = O.build_targets(x, mask, cfg, normalize)                       # oracle, engine_for_pretraining.py:43-63
+    pred = _rand((Bc * nm, 1536), dev, 5)
+    row_loss = torch.empty(Bc * nm, dtype=F32, device=dev)
+    loss = torch.empty(1, dtype=F32, device=dev)
+    dpred = torch.empty_like(pred)
+    tgt = torch.empty(Bc * nm, 1536, dtype=F32, device=dev)
+    ops.target_mse(x.to(dev), 2, 16, msk, pred, normalize, 1.0, row_loss, loss, dpred, tgt)
+    assert torch.allclose(tgt.cpu(), labels.reshape(Bc * nm, 1536), rtol=2e-4, atol=2e-5)
+    pr = pred.float().cpu().requires_grad_(True)
+    ref = O.mse_loss(pr, labels.reshape(Bc * nm, 1536))
+    ref.backward()
+    assert float(loss.item()) == pytest.approx(float(ref), rel=1e-5)
+    assert _rel(dpred.cpu(), pr.grad) < 4e-3
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_sumsq_adamw_cast(dev):
+    from mofo_amd import ops
+    n = 1024 * 37
+    g = _rand((n,), dev, 1, 0.3, F32)
+    partial = torch.empty(1024, dtype=F32, device=dev)
+    norm = torch.empty(1, dtype=F32, device=dev)
+    ops.sumsq_norm(g, partial, norm)
+    assert float(norm.item()) == pytest.approx(float(g.double().norm()), rel=1e-6)
+    p = _rand((n,), dev, 2, 1.0, F32)
+    grp = (torch.arange(37) % 3 == 0).to(torch.uint8).to(dev)       # group 1 = no decay here
+    m = torch.zeros_like(p)
+    v = torch.zeros_like(p)
+    pb = torch.empty(n, dtype=BF16, device=dev)
+    pr, mr, vr = p.clone().double(), m.clone().double(), v.clone().double()
+    lr0, wd0, lr1, wd1 = 1.5e-4, 0.05, 3e-4, 0.0
+    for step in (1, 2, 3):
+        ops.adamw(p, g, m, v, pb, grp, lr0, wd0, lr1, wd1, 0.9, 0.95, 1e-8, step)
+        lr = torch.where(grp.repeat_interleave(1024).bool(), lr1, lr0).double()
+        wd = torch.where(grp.repeat_interleave(1024).bool(), wd1, wd0).double()
+        gd = g.double()
+        pr = pr * (1 - lr * wd)
+        mr = 0.9 * mr + 0.1 * gd
+        vr = 0.95 * vr + 0.05 * gd * gd
+        pr = pr - lr / (1 - 0.9 ** step) * mr / (vr.sqrt() / math.sqrt(1 - 0.95 ** step) + 1e-8)
+    assert _rel(p, pr) < 1e-6
+    assert _rel(m, mr) < 1e-6 and _rel(v, vr) < 1e-6
+    assert torch.equal(pb, p.to(BF16))
+    # clipping: max_norm below the norm scales the gradient by max_norm / (norm + 1e-6)
+    p2, m2, v2 = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    ops.adamw(p2, g, m2, v2, None, grp, lr0, 0.0, lr0, 0.0, 0.9, 0.95, 1e-8, 1, grad_norm=norm, max_norm=0.5)
+    coef = 0.5 / (float(norm.item()) + 1e-6)
+    assert _rel(m2, 0.1 * g * coef) < 1e-5
+    dst = torch.empty(n, dtype=BF16, device=dev)
+    ops.cast_bf16(p, dst)
+    assert torch.equal(dst, p.to(BF16))
