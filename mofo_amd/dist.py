@@ -1,0 +1,62 @@
+"""Data parallelism for the pretraining step: one process per GPU (torch.distributed, backend 'nccl' = RCCL over xGMI),
+a full replica per rank, and ONE exchange per step -- the gradient all-reduce (reference: DistributedDataParallel at
+run_mae_pretraining.py:225-227, 376.8 MB fp32 per step).
+
+MI355X-first: gradients already live in one flat buffer, so the buckets are contiguous RANGES of that buffer
+(PretrainRuntime.segments: decoder first, then encoder blocks from the top) -- no bucket copies, no autograd hooks, no
+graph walk (the reference passes find_unused_parameters=True).  Each range is all-reduced asynchronously as soon as the
+hand-written backward has enqueued its last wgrad; RCCL runs it on its own stream behind an event, overlapping the rest
+of backward.  SUM reduction of gradients that were pre-scaled by 1/world (loss kernel grad_scale) == DDP's mean."""
+from typing import List
+
+import torch
+import torch.distributed as dist
+
+
+class GradSync:
+    def __init__(self, model, process_group=None):
+        self.model = model
+        self.pg = process_group
+        self.handles: List = []
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        self.launched: List[tuple] = []
+
+    def install(self):
+        rt = self.model.runtime()
+        rt.segment_hook = self._on_segment
+        self.model._grad_sync = self
+        return self
+
+    def _on_segment(self, idx, lo, hi):
+        self.launched.append((idx, lo, hi))
+        if not self.enabled:
+            return
+        g = self.model.runtime().store.grads[lo:hi]
+        self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
+
+    def finish(self):
+        """join the outstanding all-reduces (the current stream waits; the host does not block on nccl)"""
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+        self.launched.clear()
+
+
+class DataParallel(torch.nn.Module):
+    """Thin stand-in for torch DDP at run_mae_pretraining.py:225-227: exposes ``.module``, broadcasts rank 0's parameters
+    once (one flat broadcast), and arranges the per-step gradient exchange."""
+
+    def __init__(self, module, device_ids=None, process_group=None, **_ignored):
+        super().__init__()
+        self.module = module
+        self.sync = GradSync(module, process_group).install()
+        if self.sync.enabled:
+            dist.broadcast(module.runtime().store.params, src=0, group=process_group)
+        self.world_size = dist.get_world_size(process_group) if self.sync.enabled else 1
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+    def forward_loss(self, x, mask, normlize_target=True, grad_scale=None):
+        gs = 1.0 / self.world_size if grad_scale is None else grad_scale
+        return self.module.forward_loss(x, mask, normlize_target, gs)

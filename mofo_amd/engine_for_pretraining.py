@@ -1,0 +1,107 @@
+"""Drop-in for the reference's ``engine_for_pretraining.py``: ``train_one_epoch`` / ``train_one_epoch_BB`` with the
+reference's signature and returned meter dict.  Per step (engine_for_pretraining.py:29-69,168-208):
+  schedule writes -> batch to device -> [target build + forward + MSE] -> finite check -> zero_grad ->
+  loss_scaler(backward, grad norm / clip, optimizer step) -> meters.
+Not reproduced on purpose: the debug block at :74-166 that writes B x 16 x 3 PNGs every step, and in the BB
+variant the bbox rasterisation at :243-249 whose result is never used (the loss weighting is commented out at :294-303).
+"""
+import math
+import sys
+from typing import Iterable
+
+import torch
+
+from . import utils
+
+
+def _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_norm, normlize_target, it, lr_schedule_values,
+                 wd_schedule_values):
+    if lr_schedule_values is not None or wd_schedule_values is not None:
+        for param_group in optimizer.param_groups:
+            if lr_schedule_values is not None:
+                param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
+            if wd_schedule_values is not None and param_group["weight_decay"] > 0:
+                param_group["weight_decay"] = wd_schedule_values[it]
+    raw = getattr(model, "module", model)
+    # mask arrives from the loader as float64 [B, N] (1 = masked); the visible count is known on the host -> no device sync
+    if not bool_masked_pos.is_cuda and raw._n_vis_cache is None:
+        raw.set_visible_tokens(int((bool_masked_pos[0].reshape(-1) == 0).sum()))
+    mask = bool_masked_pos.flatten(1).to(torch.uint8 if not bool_masked_pos.is_cuda else bool_masked_pos.dtype)
+    loss = model.forward_loss(videos, mask, normlize_target) if hasattr(model, "forward_loss") else None
+    if loss is None:
+        raise TypeError("model must be a mofo_amd PretrainVisionTransformer (optionally wrapped in mofo_amd.dist.DataParallel)")
+    loss_value = loss.item()
+    raw.check_status()
+    if not math.isfinite(loss_value):
+        print("Loss is {}, stopping training".format(loss_value))
+        sys.exit(1)
+    optimizer.zero_grad()
+    grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False)
+    loss_scale_value = loss_scaler.state_dict()["scale"]
+    torch.cuda.synchronize()
+    return loss_value, grad_norm, loss_scale_value
+
+
+def _train(model, data_loader, optimizer, device, epoch, loss_scaler, max_norm, patch_size, normlize_target, log_writer,
+           lr_scheduler, start_steps, lr_schedule_values, wd_schedule_values, has_bbox):
+    model.train()
+    if patch_size != 16:
+        raise NotImplementedError("the fused target/loss kernel is built for patch_size 16")
+    metric_logger = utils.MetricLogger(delimiter="  ")
+    metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    metric_logger.add_meter('min_lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    header = 'Epoch: [{}]'.format(epoch)
+    for step, batch in enumerate(metric_logger.log_every(data_loader, 10, header)):
+        it = start_steps + step
+        if has_bbox:
+            videos, _bbox, bool_masked_pos = batch
+        else:
+            videos, bool_masked_pos = batch
+        loss_value, grad_norm, loss_scale_value = _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_norm,
+                                                               normlize_target, it, lr_schedule_values, wd_schedule_values)
+        metric_logger.update(loss=loss_value)
+        metric_logger.update(loss_scale=loss_scale_value)
+        min_lr, max_lr = 10., 0.
+        for group in optimizer.param_groups:
+            min_lr = min(min_lr, group["lr"])
+            max_lr = max(max_lr, group["lr"])
+        metric_logger.update(lr=max_lr)
+        metric_logger.update(min_lr=min_lr)
+        weight_decay_value = None
+        for group in optimizer.param_groups:
+            if group["weight_decay"] > 0:
+                weight_decay_value = group["weight_decay"]
+        metric_logger.update(weight_decay=weight_decay_value)
+        metric_logger.update(grad_norm=grad_norm)
+        if log_writer is not None:
+            log_writer.update(loss=loss_value, head="loss")
+            log_writer.update(loss_scale=loss_scale_value, head="opt")
+            log_writer.update(lr=max_lr, head="opt")
+            log_writer.update(min_lr=min_lr, head="opt")
+            log_writer.update(weight_decay=weight_decay_value, head="opt")
+            log_writer.update(grad_norm=grad_norm, head="opt")
+            log_writer.set_step()
+        if lr_scheduler is not None:
+            lr_scheduler.step_update(start_steps + step)
+    metric_logger.synchronize_between_processes()
+    print("Averaged stats:", metric_logger)
+    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+
+
+def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,
+                    device: torch.device, epoch: int, loss_scaler, max_norm: float = 0, patch_size: int = 16,
+                    normlize_target: bool = True, log_writer=None, lr_scheduler=None, start_steps=None,
+                    lr_schedule_values=None, wd_schedule_values=None):
+    """engine_for_pretraining.py:16-212"""
+    return _train(model, data_loader, optimizer, device, epoch, loss_scaler, max_norm, patch_size, normlize_target, log_writer,
+                  lr_scheduler, start_steps, lr_schedule_values, wd_schedule_values, has_bbox=False)
+
+
+def train_one_epoch_BB(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,
+                       device: torch.device, epoch: int, loss_scaler, max_norm: float = 0, patch_size: int = 16,
+                       normlize_target: bool = True, log_writer=None, lr_scheduler=None, start_steps=None,
+                       lr_schedule_values=None, wd_schedule_values=None, loss_weight=None):
+    """engine_for_pretraining.py:215-468: batches are (videos, bbox, mask); same arithmetic as train_one_epoch
+    (MSELoss(reduction='none').mean() == MSELoss()); only the mask generator upstream differs."""
+    return _train(model, data_loader, optimizer, device, epoch, loss_scaler, max_norm, patch_size, normlize_target, log_writer,
+                  lr_scheduler, start_steps, lr_schedule_values, wd_schedule_values, has_bbox=True)

@@ -1,0 +1,486 @@
+"""Drop-in for the reference's ``modeling_pretrain.py`` (same class / factory names, constructor arguments, attribute
+names and state_dict schema -- SURVEY.md 8b), executing on hand-written HIP kernels through libmofo_hip.so.
+
+    PretrainVisionTransformerEncoder   modeling_pretrain.py:23-101
+    PretrainVisionTransformerDecoder   modeling_pretrain.py:103-161
+    PretrainVisionTransformer          modeling_pretrain.py:163-266
+    pretrain_videomae_{base,large}_patch16_224, pretrain_mae_small_patch16_224   modeling_pretrain.py:268-338
+
+The torch Modules below only HOLD the parameters (so state_dict / load_state_dict / optimizers / checkpoints see the
+reference's names, shapes and [out, in] layouts); no torch compute op runs in forward or backward.  Options that the
+fast path does not implement (dropout, drop-path, layer-scale, learnable pos-emb, qk_scale override, qkv_bias=False,
+head_dim != 64) raise instead of silently computing something else.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from .runtime import BF16, F32, Dims, FlatStore, PretrainRuntime
+
+__all__ = ["PretrainVisionTransformerEncoder", "PretrainVisionTransformerDecoder", "PretrainVisionTransformer",
+           "pretrain_videomae_base_patch16_224", "pretrain_videomae_large_patch16_224", "pretrain_mae_small_patch16_224"]
+
+STATUS_BAD_MASK = 1      # a clip's visible-token count differs (the reference's reshape at :90 would raise)
+STATUS_BAD_UPSTREAM = 2  # fused loss was back-propagated with an upstream gradient != 1
+
+
+def trunc_normal_(tensor, mean=0., std=1.):
+    """modeling_pretrain.py:13-14: truncated normal clipped at +-std"""
+    return nn.init.trunc_normal_(tensor, mean=mean, std=std, a=-std, b=std)
+
+
+def _unsupported(**opts):
+    bad = {k: v for k, v in opts.items() if v}
+    if bad:
+        raise NotImplementedError(f"mofo_amd fast path does not implement {bad}; the reference pretraining recipe leaves them off")
+
+
+def _ln_eps(norm_layer, dim):
+    probe = norm_layer(dim)
+    if not isinstance(probe, nn.LayerNorm) or not probe.elementwise_affine:
+        raise NotImplementedError("norm_layer must build an affine nn.LayerNorm")
+    return float(probe.eps)
+
+
+# ----------------------------------------------------------------------------------------- parameter holders
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover
+        raise RuntimeError("parameter holder: compute runs in libmofo_hip, call the enclosing model")
+
+
+class PatchEmbed(_Holder):
+    """modeling_finetune.py:226-240 (parameters and bookkeeping attributes only)"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, num_frames=16, tubelet_size=2):
+        super().__init__()
+        img_size = (img_size, img_size) if isinstance(img_size, int) else tuple(img_size)
+        patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.tubelet_size = int(tubelet_size)
+        self.img_size, self.patch_size = img_size, patch_size
+        self.num_frames = num_frames
+        self.num_patches = (img_size[1] // patch_size[1]) * (img_size[0] // patch_size[0]) * (num_frames // self.tubelet_size)
+        self.proj = nn.Conv3d(in_chans, embed_dim, kernel_size=(self.tubelet_size, patch_size[0], patch_size[1]),
+                              stride=(self.tubelet_size, patch_size[0], patch_size[1]))
+
+
+class Attention(_Holder):
+    """modeling_finetune.py:54-76"""
+
+    def __init__(self, dim, num_heads):
+        super().__init__()
+        self.num_heads = num_heads
+        self.scale = (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=False)
+        self.q_bias = nn.Parameter(torch.zeros(dim))
+        self.v_bias = nn.Parameter(torch.zeros(dim))
+        self.proj = nn.Linear(dim, dim)
+
+
+class Mlp(_Holder):
+    """modeling_finetune.py:34-42"""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+
+class Block(_Holder):
+    """modeling_finetune.py:194-214 with gamma_1 = gamma_2 = None (init_values = 0)"""
+
+    def __init__(self, dim, num_heads, mlp_ratio, eps):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=eps)
+        self.attn = Attention(dim, num_heads)
+        self.norm2 = nn.LayerNorm(dim, eps=eps)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.gamma_1, self.gamma_2 = None, None
+
+
+def _init_weights(m):
+    """modeling_pretrain.py:60-67"""
+    if isinstance(m, nn.Linear):
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif isinstance(m, nn.LayerNorm):
+        nn.init.constant_(m.bias, 0)
+        nn.init.constant_(m.weight, 1.0)
+
+
+def _check_heads(dim, heads):
+    if dim % heads or dim // heads != 64:
+        raise NotImplementedError(f"attention kernels are built for head_dim 64 (got dim={dim}, heads={heads})")
+
+
+# ----------------------------------------------------------------------------------------- autograd glue
+class _EncoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, mod, w):
+        rt = mod._rt
+        rt.store.refresh_shadow()
+        out = rt.encoder_forward(w)
+        ctx.mod, ctx.w = mod, w
+        return out.view(w.B, w.n_vis, -1).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, w = ctx.mod, ctx.w
+        mod._ensure_grads()
+        w.d_encout.copy_(g.reshape(w.Me, -1))
+        mod._rt.encoder_backward(w, w.d_encout)
+        return None, None, None
+
+
+class _DecoderFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mod, w, n_ret):
+        rt = mod._rt
+        rt.store.refresh_shadow()
+        w.x_full.copy_(x)
+        pred = rt.decoder_forward(w, w.x_full, n_ret)
+        ctx.mod, ctx.w, ctx.n_ret = mod, w, n_ret
+        return pred.view(w.B, n_ret, -1).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, w = ctx.mod, ctx.w
+        mod._ensure_grads()
+        w.dpred.copy_(g.reshape(w.Mm, -1))
+        dx = mod._rt.decoder_backward(w, w.dpred, w.x_full, ctx.n_ret)
+        return dx.view(w.B, w.N, -1).clone(), None, None, None
+
+
+class _ModelFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, mod, w, fused, normalize, grad_scale):
+        rt = mod._rt
+        rt.store.refresh_shadow()
+        rt.forward(w)
+        ctx.mod, ctx.w, ctx.fused = mod, w, fused
+        if fused:
+            rt.loss_forward(w, normalize, grad_scale)
+            return w.loss.clone().reshape(())
+        return w.pred.view(w.B, w.n_msk, -1).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        mod, w = ctx.mod, ctx.w
+        mod._ensure_grads()
+        if ctx.fused:
+            # d(loss)/d(pred) was produced by the loss kernel for an upstream gradient of exactly 1 (what
+            # loss.backward() passes); anything else is flagged on the device and raised at the next status check.
+            w.status.bitwise_or_((g.reshape(1) != 1).to(torch.int32) * STATUS_BAD_UPSTREAM)
+        else:
+            w.dpred.copy_(g.reshape(w.Mm, -1))
+        mod._rt.backward(w)
+        return None, None, None, None, None, None
+
+
+class _FlatModule(nn.Module):
+    """Shared machinery: lazy flat-store / runtime construction on the device the parameters live on."""
+
+    _rt = None
+    _n_vis_cache = None
+
+    def _flat_order(self):
+        raise NotImplementedError
+
+    def _make_runtime(self, store):
+        raise NotImplementedError
+
+    def _apply(self, fn, *a, **k):
+        # .to() / .cuda() / .float() re-create parameter storage: drop the flat views, rebuild lazily
+        self._rt = None
+        return super()._apply(fn, *a, **k)
+
+    def runtime(self) -> PretrainRuntime:
+        rt = self._rt
+        if rt is not None and rt.store.owns():
+            return rt
+        p0 = next(self.parameters())
+        if not p0.is_cuda:
+            raise RuntimeError("mofo_amd runs on the GPU only (no CPU fallback): move the model with .to('cuda') first")
+        for n, p in self.named_parameters():
+            if p.dtype != F32:
+                raise TypeError(f"{n}: master parameters must stay fp32 (bf16 copies for the MFMA GEMMs are kept internally)")
+        order = self._flat_order()
+        named = dict(self.named_parameters())
+        assert sorted(order) == sorted(named), "flat order does not cover the parameters"
+        store = FlatStore([(n, named[n]) for n in order], p0.device, skip_decay=self.no_weight_decay())
+        self._rt = self._make_runtime(store)
+        self._anchor = torch.zeros(1, device=p0.device, requires_grad=True)
+        return self._rt
+
+    def _ensure_grads(self):
+        st = self._rt.store
+        if not st.grads_attached():   # someone did zero_grad(set_to_none=True): semantics = zero gradients
+            st.zero_grads()
+            st.attach_grads()
+
+    def _n_vis_of(self, mask):
+        if self._n_vis_cache is None:
+            self._n_vis_cache = int((~mask[0].reshape(-1).bool()).sum().item())   # one sync, first call only
+        return self._n_vis_cache
+
+    def set_visible_tokens(self, n_vis: int):
+        """visible tokens per clip (known on the host: (1-mask_ratio) * patches per frame * frames/2); avoids a device sync"""
+        self._n_vis_cache = int(n_vis)
+
+    def check_status(self, w=None):
+        """raise if the device-side status word is set (one small D2H read; call where the loss is read anyway)"""
+        for ws in ([w] if w is not None else list(self._rt._ws.values())):
+            st = int(ws.status.item())
+            if st & STATUS_BAD_MASK:
+                ws.status.zero_()
+                raise RuntimeError("mask: clips have different numbers of visible tokens (reference reshape at "
+                                   "modeling_pretrain.py:90 requires them equal) or the count differs from set_visible_tokens()")
+            if st & STATUS_BAD_UPSTREAM:
+                ws.status.zero_()
+                raise RuntimeError("forward_loss() was back-propagated with an upstream gradient != 1; use forward() + a torch loss for that")
+
+
+def _block_names(prefix, depth):
+    out = []
+    for i in range(depth):
+        p = f"{prefix}blocks.{i}."
+        out += [p + n for n in ("norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias", "attn.qkv.weight", "attn.proj.weight",
+                                "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight",
+                                "mlp.fc2.bias")]
+    return out
+
+
+# ----------------------------------------------------------------------------------------- encoder
+class PretrainVisionTransformerEncoder(_FlatModule):
+    """modeling_pretrain.py:23-101"""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=0, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, init_values=None, tubelet_size=2,
+                 use_learnable_pos_emb=False, num_frames=16):
+        super().__init__()
+        _unsupported(qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate,
+                     init_values=init_values, use_learnable_pos_emb=use_learnable_pos_emb, num_classes=num_classes,
+                     no_qkv_bias=not qkv_bias)
+        _check_heads(embed_dim, num_heads)
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.depth, self.num_heads, self.mlp_ratio = depth, num_heads, mlp_ratio
+        self.eps = _ln_eps(norm_layer, embed_dim)
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      num_frames=num_frames, tubelet_size=tubelet_size)
+        self.in_chans = in_chans
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, self.eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=self.eps)
+        self.head = nn.Identity()
+        self.apply(_init_weights)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def _dims(self):
+        pe = self.patch_embed
+        return Dims(img_size=pe.img_size[0], patch_size=pe.patch_size[0], tubelet=pe.tubelet_size, num_frames=pe.num_frames,
+                    in_chans=self.in_chans, enc_dim=self.embed_dim, enc_depth=self.depth, enc_heads=self.num_heads,
+                    mlp_ratio=self.mlp_ratio, eps=self.eps, dec_depth=0)
+
+    def _flat_order(self):
+        return ["patch_embed.proj.weight", "patch_embed.proj.bias"] + _block_names("", self.depth) + ["norm.weight", "norm.bias"]
+
+    def _make_runtime(self, store):
+        return PretrainRuntime(self._dims(), store, enc_prefix="", dec_prefix=None, top=False)
+
+    def forward_features(self, x, mask):
+        rt = self.runtime()
+        w = rt.ws(x.shape[0], self._n_vis_of(mask))
+        rt.set_inputs(w, x, mask)
+        return _EncoderFn.apply(self._anchor, self, w)
+
+    def forward(self, x, mask):
+        return self.head(self.forward_features(x, mask))
+
+
+# ----------------------------------------------------------------------------------------- decoder
+class PretrainVisionTransformerDecoder(_FlatModule):
+    """modeling_pretrain.py:103-161"""
+
+    def __init__(self, patch_size=16, num_classes=768, embed_dim=768, depth=12,
+                 num_heads=12, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, init_values=None, num_patches=196, tubelet_size=2):
+        super().__init__()
+        _unsupported(qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate, drop_path_rate=drop_path_rate,
+                     init_values=init_values, no_qkv_bias=not qkv_bias)
+        _check_heads(embed_dim, num_heads)
+        self.num_classes = num_classes
+        assert num_classes == 3 * tubelet_size * patch_size ** 2
+        self.num_features = self.embed_dim = embed_dim
+        self.patch_size = patch_size
+        self.tubelet_size = tubelet_size
+        self.num_patches = num_patches
+        self.depth, self.num_heads, self.mlp_ratio = depth, num_heads, mlp_ratio
+        self.eps = _ln_eps(norm_layer, embed_dim)
+        self.blocks = nn.ModuleList([Block(embed_dim, num_heads, mlp_ratio, self.eps) for _ in range(depth)])
+        self.norm = nn.LayerNorm(embed_dim, eps=self.eps)
+        self.head = nn.Linear(embed_dim, num_classes)
+        self.apply(_init_weights)
+
+    def get_num_layers(self):
+        return len(self.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token'}
+
+    def get_classifier(self):
+        return self.head
+
+    def _flat_order(self):
+        return _block_names("", self.depth) + ["norm.weight", "norm.bias", "head.weight", "head.bias"]
+
+    def _make_runtime(self, store):
+        d = Dims(patch_size=self.patch_size, tubelet=self.tubelet_size, dec_dim=self.embed_dim, dec_depth=self.depth,
+                 dec_heads=self.num_heads, mlp_ratio=self.mlp_ratio, eps=self.eps, patch_out=self.num_classes, enc_depth=0)
+        return PretrainRuntime(d, store, enc_prefix=None, dec_prefix="", top=False)
+
+    def forward(self, x, return_token_num):
+        rt = self.runtime()
+        B, N, _ = x.shape
+        n_ret = return_token_num if return_token_num > 0 else N
+        w = rt.ws(B, N - n_ret, N)
+        return _DecoderFn.apply(x if x.requires_grad else x.detach().requires_grad_(True), self, w, n_ret)
+
+
+# ----------------------------------------------------------------------------------------- full model
+class PretrainVisionTransformer(_FlatModule):
+    """modeling_pretrain.py:163-266"""
+
+    def __init__(self, img_size=224, patch_size=16, encoder_in_chans=3, encoder_num_classes=0, encoder_embed_dim=768,
+                 encoder_depth=12, encoder_num_heads=12, decoder_num_classes=1536, decoder_embed_dim=512, decoder_depth=8,
+                 decoder_num_heads=8, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0., norm_layer=nn.LayerNorm, init_values=0., use_learnable_pos_emb=False, tubelet_size=2,
+                 num_classes=0, in_chans=0, num_frames=16):
+        super().__init__()
+        self.encoder = PretrainVisionTransformerEncoder(
+            img_size=img_size, patch_size=patch_size, in_chans=encoder_in_chans, num_classes=encoder_num_classes,
+            embed_dim=encoder_embed_dim, depth=encoder_depth, num_heads=encoder_num_heads, mlp_ratio=mlp_ratio,
+            qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+            drop_path_rate=drop_path_rate, norm_layer=norm_layer, init_values=init_values, tubelet_size=tubelet_size,
+            use_learnable_pos_emb=use_learnable_pos_emb, num_frames=num_frames)
+        self.decoder = PretrainVisionTransformerDecoder(
+            patch_size=patch_size, num_patches=self.encoder.patch_embed.num_patches, num_classes=decoder_num_classes,
+            embed_dim=decoder_embed_dim, depth=decoder_depth, num_heads=decoder_num_heads, mlp_ratio=mlp_ratio,
+            qkv_bias=qkv_bias, qk_scale=qk_scale, drop_rate=drop_rate, attn_drop_rate=attn_drop_rate,
+            drop_path_rate=drop_path_rate, norm_layer=norm_layer, init_values=init_values, tubelet_size=tubelet_size)
+        self.encoder_to_decoder = nn.Linear(encoder_embed_dim, decoder_embed_dim, bias=False)
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, decoder_embed_dim))
+        trunc_normal_(self.mask_token, std=.02)
+
+    def get_num_layers(self):
+        return len(self.encoder.blocks) + len(self.decoder.blocks)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'pos_embed', 'cls_token', 'mask_token'}
+
+    def _flat_order(self):
+        e, d = self.encoder, self.decoder
+        return (["encoder.patch_embed.proj.weight", "encoder.patch_embed.proj.bias"] + _block_names("encoder.", e.depth)
+                + ["encoder.norm.weight", "encoder.norm.bias", "encoder_to_decoder.weight", "mask_token"]
+                + _block_names("decoder.", d.depth) + ["decoder.norm.weight", "decoder.norm.bias", "decoder.head.weight", "decoder.head.bias"])
+
+    def _make_runtime(self, store):
+        e, d = self.encoder, self.decoder
+        ed = e._dims()
+        dims = Dims(img_size=ed.img_size, patch_size=ed.patch_size, tubelet=ed.tubelet, num_frames=ed.num_frames, in_chans=ed.in_chans,
+                    enc_dim=ed.enc_dim, enc_depth=ed.enc_depth, enc_heads=ed.enc_heads, dec_dim=d.embed_dim, dec_depth=d.depth,
+                    dec_heads=d.num_heads, mlp_ratio=e.mlp_ratio, eps=e.eps, patch_out=d.num_classes)
+        if d.eps != e.eps or d.mlp_ratio != e.mlp_ratio:
+            raise NotImplementedError("encoder and decoder must share eps and mlp_ratio")
+        return PretrainRuntime(dims, store, enc_prefix="encoder.", dec_prefix="decoder.", top=True)
+
+    # -- helpers -------------------------------------------------------------------------------------------------
+    def _prepare(self, x, mask):
+        rt = self.runtime()
+        w = rt.ws(x.shape[0], self._n_vis_of(mask))
+        rt.set_inputs(w, x, mask)
+        return rt, w
+
+    def input_buffers(self, batch_size: int, n_vis: int):
+        """(clips f32 [B,C,T,H,W], mask u8 [B,N]) persistent device buffers: a loader that writes batches straight into
+        them (or a synthetic generator) skips the per-step staging copy."""
+        self.set_visible_tokens(n_vis)
+        w = self.runtime().ws(batch_size, n_vis)
+        return w.clips, w.mask_u8
+
+    # -- reference API -------------------------------------------------------------------------------------------
+    def forward(self, x, mask):
+        """[B,3,T,H,W] f32, mask bool [B,N] (True = masked) -> [B, N_mask, 1536] f32 predictions, autograd-connected."""
+        rt, w = self._prepare(x, mask)
+        return _ModelFn.apply(self._anchor, self, w, False, True, 1.0)
+
+    # -- fused fast path -----------------------------------------------------------------------------------------
+    def forward_loss(self, x, mask, normlize_target=True, grad_scale=1.0):
+        """model forward + reconstruction target + nn.MSELoss fused (engine_for_pretraining.py:43-67): returns the scalar
+        loss; ``loss.backward()`` runs the hand-written backward.  ``grad_scale`` pre-multiplies d(loss) (1/world_size
+        turns the data-parallel SUM all-reduce into DDP's mean)."""
+        rt, w = self._prepare(x, mask)
+        return _ModelFn.apply(self._anchor, self, w, True, bool(normlize_target), float(grad_scale))
+
+
+# ----------------------------------------------------------------------------------------- factories
+def _finish(model, pretrained, kwargs):
+    model.default_cfg = {'url': '', 'num_classes': 400, 'input_size': (3, 224, 224), 'pool_size': None, 'crop_pct': .9,
+                         'interpolation': 'bicubic', 'mean': (0.5, 0.5, 0.5), 'std': (0.5, 0.5, 0.5)}
+    if pretrained:
+        checkpoint = torch.load(kwargs["init_ckpt"], map_location="cpu")
+        model.load_state_dict(checkpoint["model"])
+    return model
+
+
+def _drop(kwargs):
+    kw = dict(kwargs)
+    kw.pop("init_ckpt", None)
+    kw.pop("drop_block_rate", None)
+    return kw
+
+
+def pretrain_mae_small_patch16_224(pretrained=False, **kwargs):
+    """modeling_pretrain.py:268-290"""
+    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=384, encoder_depth=12, encoder_num_heads=6,
+                                      encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=192, decoder_num_heads=3,
+                                      mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
+    return _finish(model, pretrained, kwargs)
+
+
+def pretrain_videomae_base_patch16_224(pretrained=False, **kwargs):
+    """modeling_pretrain.py:292-314"""
+    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=768, encoder_depth=12, encoder_num_heads=12,
+                                      encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=384, decoder_num_heads=6,
+                                      mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
+    return _finish(model, pretrained, kwargs)
+
+
+def pretrain_videomae_large_patch16_224(pretrained=False, **kwargs):
+    """modeling_pretrain.py:316-338"""
+    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=1024, encoder_depth=24, encoder_num_heads=16,
+                                      encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=512, decoder_num_heads=8,
+                                      mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
+    return _finish(model, pretrained, kwargs)
+
+
+_REGISTRY = {f.__name__: f for f in (pretrain_mae_small_patch16_224, pretrain_videomae_base_patch16_224,
+                                     pretrain_videomae_large_patch16_224)}
+
+
+def create_model(name, pretrained=False, **kwargs):
+    """stand-in for timm.models.create_model as used at run_mae_pretraining.py:135-144 (drops None kwargs)"""
+    return _REGISTRY[name](pretrained=pretrained, **{k: v for k, v in kwargs.items() if v is not None})

@@ -1,0 +1,125 @@
+"""Drop-in for the AdamW path of the reference's ``optim_factory.py`` (create_optimizer / get_parameter_groups,
+optim_factory.py:49-127): same two parameter groups (decayed: >=2-D weights; not decayed: 1-D tensors, ``.bias`` and the
+model's ``no_weight_decay()`` names), each carrying ``lr_scale`` -- but the update itself is ONE fused HIP kernel over
+the model's flat parameter / gradient / moment buffers, which also refreshes the bf16 copies the GEMMs read.
+The other 20 optimizers of the reference factory are not used by the pretraining recipe (PRETRAIN.md:25-26) and are
+out of scope; asking for one raises."""
+import torch
+
+from . import ops
+
+
+def get_parameter_groups(model, weight_decay=1e-5, skip_list=(), get_num_layer=None, get_layer_scale=None):
+    """optim_factory.py:49-88 (the layer-decay branch belongs to fine-tuning and is not built)."""
+    if get_num_layer is not None or get_layer_scale is not None:
+        raise NotImplementedError("layer-wise lr decay is a fine-tuning feature (out of scope)")
+    groups = {"decay": {"weight_decay": weight_decay, "params": [], "lr_scale": 1.},
+              "no_decay": {"weight_decay": 0., "params": [], "lr_scale": 1.}}
+    names = {"decay": [], "no_decay": []}
+    for name, param in model.named_parameters():
+        if not param.requires_grad:
+            continue
+        g = "no_decay" if (len(param.shape) == 1 or name.endswith(".bias") or name in skip_list) else "decay"
+        groups[g]["params"].append(param)
+        names[g].append(name)
+    # reference order of creation = order of first appearance in named_parameters()
+    first = next(iter(model.named_parameters()))[0]
+    order = ["no_decay", "decay"] if first in names["no_decay"] else ["decay", "no_decay"]
+    return [groups[k] for k in order if groups[k]["params"]], {k: names[k] for k in order}
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside the sqrt) on flat buffers.
+
+    ``param_groups`` keeps the reference's keys (lr, weight_decay, lr_scale, betas, eps) so the engine's per-step
+    schedule writes (engine_for_pretraining.py:31-37) work unchanged.  ``grad_norm`` / ``max_norm`` let the caller fuse
+    clip_grad_norm_ (utils.py:359) into the same kernel without a host sync."""
+
+    def __init__(self, model, param_groups, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+        super().__init__(param_groups, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.model = model
+        self._store = None
+        self._step = 0
+        self.exp_avg = None
+        self.exp_avg_sq = None
+        self._bind()
+
+    def _bind(self):
+        rt = self.model.runtime()
+        st = rt.store
+        if self._store is not st:
+            if self._store is not None and self._step > 0:
+                raise RuntimeError("the model's parameters were moved after optimisation started; optimizer state would be lost")
+            self._store = st
+            self.exp_avg = torch.zeros_like(st.params)
+            self.exp_avg_sq = torch.zeros_like(st.params)
+        return rt, st
+
+    def zero_grad(self, set_to_none: bool = False):
+        _, st = self._bind()
+        st.zero_grads()
+        if not st.grads_attached():
+            st.attach_grads()
+
+    def _group(self, decayed: bool):
+        for g in self.param_groups:
+            if (g["weight_decay"] > 0) == decayed or len(self.param_groups) == 1:
+                return g
+        # both groups may carry weight_decay 0 (wd schedule at 0): fall back to creation tags
+        for g in self.param_groups:
+            if g.get("_decayed", None) == decayed:
+                return g
+        return self.param_groups[0]
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_norm=None, max_norm=0.0):
+        if closure is not None:
+            raise NotImplementedError("closure")
+        _, st = self._bind()
+        g0 = next(g for g in self.param_groups if g["_decayed"]) if any(g.get("_decayed") for g in self.param_groups) else self.param_groups[0]
+        g1 = next((g for g in self.param_groups if not g["_decayed"]), g0)
+        self._step += 1
+        b1, b2 = g0["betas"]
+        ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group,
+                  float(g0["lr"]), float(g0["weight_decay"]), float(g1["lr"]), float(g1["weight_decay"]),
+                  float(b1), float(b2), float(g0["eps"]), self._step, grad_norm=grad_norm,
+                  max_norm=float(max_norm) if max_norm else 0.0)
+        st.mark_shadow_fresh()
+
+    # checkpoint: flat moments + step (the model's state_dict carries the parameters under the reference's names)
+    def state_dict(self):
+        return {"state": {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "format": "mofo_amd.flat.v1"},
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._bind()
+        s = sd["state"]
+        if s.get("format") != "mofo_amd.flat.v1" or s["exp_avg"].numel() != self.exp_avg.numel():
+            raise ValueError("optimizer state is not a mofo_amd flat AdamW state for this model")
+        self._step = int(s["step"])
+        self.exp_avg.copy_(s["exp_avg"])
+        self.exp_avg_sq.copy_(s["exp_avg_sq"])
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g.update({k: v for k, v in saved.items() if k != "params"})
+
+
+def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):
+    """optim_factory.py:91-175 for ``--opt adamw`` (the pretraining recipe)."""
+    opt_lower = args.opt.lower().split('_')[-1]
+    if opt_lower != 'adamw':
+        raise NotImplementedError(f"optimizer '{args.opt}': only adamw (the pretraining recipe, PRETRAIN.md:25) is built")
+    model = getattr(model, "module", model)
+    weight_decay = args.weight_decay
+    skip = skip_list if skip_list is not None else (model.no_weight_decay() if hasattr(model, 'no_weight_decay') else {})
+    groups, names = get_parameter_groups(model, weight_decay, skip, get_num_layer, get_layer_scale)
+    if not (weight_decay and filter_bias_and_bn):
+        for g in groups:
+            g["weight_decay"] = weight_decay or 0.
+    for g, k in zip(groups, names):
+        g["_decayed"] = (k == "decay")
+    kw = dict(lr=args.lr, weight_decay=0.)
+    if getattr(args, 'opt_eps', None) is not None:
+        kw['eps'] = args.opt_eps
+    if getattr(args, 'opt_betas', None) is not None:
+        kw['betas'] = tuple(args.opt_betas)
+    return FusedAdamW(model, groups, **kw)

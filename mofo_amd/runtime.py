@@ -1,0 +1,483 @@
+"""Host-side runtime of the pretraining hot path: flat parameter storage, a per-batch-size workspace, and the fixed
+sequence of C-ABI kernel launches that makes up forward and backward.
+
+Design (MI355X-first, not a translation of the reference's autograd graph):
+  * every parameter lives in ONE flat fp32 buffer (+ flat fp32 grads, + a flat bf16 shadow that the MFMA GEMMs read);
+    torch Parameters are views into it, so the optimizer is one fused kernel over the buffer and the data-parallel
+    all-reduce runs on contiguous ranges of the gradient buffer with no bucket copies;
+  * all activations of a given batch size are preallocated once (288 GB of HBM: nothing is recomputed), so a step is a
+    static list of launches -- replayable without Python-side allocation and capturable into a hipGraph;
+  * the residual stream is fp32, GEMM operands are bf16, LayerNorm / softmax statistics / the loss are fp32.
+Reference arithmetic: modeling_pretrain.py:83-101,152-161,253-266; modeling_finetune.py:44-51,78-98,216-223,242-248;
+engine_for_pretraining.py:43-67.
+"""
+import math
+from dataclasses import dataclass
+from types import SimpleNamespace as NS
+from typing import Callable, Dict, List, Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+CHUNK = 1024
+
+
+@dataclass(frozen=True)
+class Dims:
+    img_size: int = 224
+    patch_size: int = 16
+    tubelet: int = 2
+    num_frames: int = 16
+    in_chans: int = 3
+    enc_dim: int = 768
+    enc_depth: int = 12
+    enc_heads: int = 12
+    dec_dim: int = 384
+    dec_depth: int = 4
+    dec_heads: int = 6
+    mlp_ratio: float = 4.0
+    eps: float = 1e-6
+    patch_out: int = 1536  # decoder_num_classes
+
+    @property
+    def grid(self):
+        g = self.img_size // self.patch_size
+        return (self.num_frames // self.tubelet, g, g)
+
+    @property
+    def num_patches(self):
+        t, h, w = self.grid
+        return t * h * w
+
+    @property
+    def patch_dim(self):
+        return self.in_chans * self.tubelet * self.patch_size ** 2
+
+
+def sincos_table(n_pos: int, dim: int) -> torch.Tensor:
+    """modeling_finetune.py:252-262 (float64 angles, sin on even / cos on odd columns, cast to f32); [n_pos, dim]."""
+    j = np.arange(dim)
+    ang = np.arange(n_pos, dtype=np.float64)[:, None] / np.power(10000, 2 * (j // 2) / dim)[None, :]
+    ang[:, 0::2] = np.sin(ang[:, 0::2])
+    ang[:, 1::2] = np.cos(ang[:, 1::2])
+    return torch.from_numpy(ang.astype(np.float32))
+
+
+def _is_no_decay(name: str, shape, skip) -> bool:
+    """optim_factory.py:56-61"""
+    return len(shape) == 1 or name.endswith(".bias") or name in skip
+
+
+def _align(n: int, a: int = CHUNK) -> int:
+    return (n + a - 1) // a * a
+
+
+# ======================================================================================================= flat store
+class FlatStore:
+    """All parameters of a module tree in one fp32 buffer; Parameters become views (data AND grad)."""
+
+    def __init__(self, named_params: List[Tuple[str, torch.nn.Parameter]], device, skip_decay=()):
+        self.device = device
+        self.names = [n for n, _ in named_params]
+        self.offset: Dict[str, int] = {}
+        self.shape: Dict[str, Tuple[int, ...]] = {}
+        plist = dict(named_params)
+        groups = []  # (offset, length, no_decay)
+        off = 0
+        done = set()
+        for name, p in named_params:
+            if name in done:
+                continue
+            if name.endswith("attn.q_bias"):
+                # fused qkv bias [3D] = (q_bias | zeros | v_bias): the reference concatenates exactly this every forward
+                # (modeling_finetune.py:82); the zero third is not a parameter and never moves (its gradient stays 0).
+                vname = name[: -len("q_bias")] + "v_bias"
+                d = p.numel()
+                self.offset[name], self.offset[vname] = off, off + 2 * d
+                self.shape[name], self.shape[vname] = tuple(p.shape), tuple(plist[vname].shape)
+                groups.append((off, 3 * d, True))
+                done.update((name, vname))
+                off = _align(off + 3 * d)
+                continue
+            self.offset[name] = off
+            self.shape[name] = tuple(p.shape)
+            groups.append((off, p.numel(), _is_no_decay(name, p.shape, skip_decay)))
+            done.add(name)
+            off = _align(off + p.numel())
+        self.total = off
+        self.params = torch.zeros(self.total, dtype=F32, device=device)
+        self.grads = torch.zeros(self.total, dtype=F32, device=device)
+        self.shadow = torch.zeros(self.total, dtype=BF16, device=device)
+        cg = np.ones(self.total // CHUNK, dtype=np.uint8)  # 1 = no-decay group, 0 = decay group
+        for o, n, nd in groups:
+            if not nd:
+                cg[o // CHUNK: (o + n + CHUNK - 1) // CHUNK] = 0
+        self.chunk_group = torch.from_numpy(cg).to(device)
+        self._params = plist
+        with torch.no_grad():
+            for name, p in named_params:
+                v = self.view(name)
+                v.copy_(p.detach().to(device=device, dtype=F32))
+                p.data = v
+        self.attach_grads()
+        self._shadow_version = -1
+        self.numel = sum(p.numel() for _, p in named_params)
+
+    def _slice(self, buf, name):
+        o = self.offset[name]
+        n = int(np.prod(self.shape[name]))
+        return buf[o:o + n]
+
+    def view(self, name):
+        return self._slice(self.params, name).view(self.shape[name])
+
+    def gview(self, name):
+        return self._slice(self.grads, name).view(self.shape[name])
+
+    def bview(self, name, rows=None):
+        """bf16 shadow as a 2-D [out, in] matrix"""
+        s = self.shape[name]
+        return self._slice(self.shadow, name).view(s[0] if rows is None else rows, -1)
+
+    def g2d(self, name):
+        s = self.shape[name]
+        return self._slice(self.grads, name).view(s[0], -1)
+
+    def fused_bias(self, qname, buf=None):
+        o = self.offset[qname]
+        d = int(np.prod(self.shape[qname]))
+        return (self.params if buf is None else buf)[o:o + 3 * d]
+
+    def range_of(self, names) -> Tuple[int, int]:
+        lo = min(self.offset[n] for n in names)
+        hi = max(self.offset[n] + int(np.prod(self.shape[n])) for n in names)
+        return lo, _align(hi)
+
+    def attach_grads(self):
+        for name, p in self._params.items():
+            p.grad = self.gview(name)
+
+    def grads_attached(self) -> bool:
+        p = next(iter(self._params.values()))
+        return p.grad is not None and p.grad.data_ptr() == self.gview(self.names[0]).data_ptr()
+
+    def owns(self, full: bool = False) -> bool:
+        """True while the Parameters still are views of the flat buffer (.to()/.half() would break that).  The cheap form
+        looks at the first and last parameter only (a module-wide .to() moves all of them)."""
+        names = self.names if full else (self.names[0], self.names[-1])
+        base = self.params.data_ptr()
+        for name in names:
+            p = self._params[name]
+            if p.data_ptr() != base + 4 * self.offset[name] or p.dtype != F32:
+                return False
+        return True
+
+    def _version(self) -> int:
+        # in-place writes through a Parameter bump that Parameter's counter, writes through store views bump the buffer's
+        return self.params._version + sum(p._version for p in self._params.values())
+
+    def refresh_shadow(self, force=False):
+        """bf16 shadow follows the fp32 masters; torch's version counters tell when someone wrote them
+        (load_state_dict, a foreign optimizer, manual init).  The fused AdamW writes the shadow itself."""
+        v = self._version()
+        if force or v != self._shadow_version:
+            ops.cast_bf16(self.params, self.shadow)
+            self._shadow_version = v
+
+    def mark_shadow_fresh(self):
+        self._shadow_version = self._version()
+
+    def zero_grads(self):
+        self.grads.zero_()
+
+
+# ======================================================================================================= runtime
+def _wsplits(P, Q, R):
+    tiles = ((P + 127) // 128) * ((Q + 127) // 128)
+    s = max(1, round(512 / tiles))
+    return int(max(1, min(s, R // 512)))
+
+
+class PretrainRuntime:
+    """Forward / backward of encoder, bridge (encoder_to_decoder + token assembly), decoder and the fused loss."""
+
+    def __init__(self, dims: Dims, store: FlatStore, enc_prefix: Optional[str] = "encoder.", dec_prefix: Optional[str] = "decoder.",
+                 top: bool = True):
+        self.d = dims
+        self.store = store
+        self.dev = store.device
+        self.enc_prefix, self.dec_prefix, self.top = enc_prefix, dec_prefix, top
+        self._ws: Dict[int, NS] = {}
+        if enc_prefix is not None:
+            self.pos_enc = sincos_table(dims.num_patches, dims.enc_dim).to(self.dev)
+            self.encW = [self._block_weights(f"{enc_prefix}blocks.{i}.") for i in range(dims.enc_depth)]
+        if top:
+            self.pos_dec = sincos_table(dims.num_patches, dims.dec_dim).to(self.dev)
+        if dec_prefix is not None:
+            self.decW = [self._block_weights(f"{dec_prefix}blocks.{i}.") for i in range(dims.dec_depth)]
+        self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
+        self.segments = self.plan_segments()
+        self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
+        self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
+
+    # ------------------------------------------------------------------ weights
+    def _block_weights(self, p):
+        s = self.store
+        return NS(prefix=p,
+                  ln1w=s.view(p + "norm1.weight"), ln1b=s.view(p + "norm1.bias"), g_ln1w=s.gview(p + "norm1.weight"), g_ln1b=s.gview(p + "norm1.bias"),
+                  qkvb=s.fused_bias(p + "attn.q_bias"), g_qb=s.gview(p + "attn.q_bias"), g_vb=s.gview(p + "attn.v_bias"),
+                  qkv=s.bview(p + "attn.qkv.weight"), g_qkv=s.g2d(p + "attn.qkv.weight"),
+                  proj=s.bview(p + "attn.proj.weight"), g_proj=s.g2d(p + "attn.proj.weight"),
+                  projb=s.view(p + "attn.proj.bias"), g_projb=s.gview(p + "attn.proj.bias"),
+                  ln2w=s.view(p + "norm2.weight"), ln2b=s.view(p + "norm2.bias"), g_ln2w=s.gview(p + "norm2.weight"), g_ln2b=s.gview(p + "norm2.bias"),
+                  fc1=s.bview(p + "mlp.fc1.weight"), g_fc1=s.g2d(p + "mlp.fc1.weight"), fc1b=s.view(p + "mlp.fc1.bias"), g_fc1b=s.gview(p + "mlp.fc1.bias"),
+                  fc2=s.bview(p + "mlp.fc2.weight"), g_fc2=s.g2d(p + "mlp.fc2.weight"), fc2b=s.view(p + "mlp.fc2.bias"), g_fc2b=s.gview(p + "mlp.fc2.bias"),
+                  names=[p + n for n in ("norm1.weight", "norm1.bias", "attn.q_bias", "attn.v_bias", "attn.qkv.weight", "attn.proj.weight",
+                                         "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")])
+
+    # ------------------------------------------------------------------ workspace
+    def _block_ws(self, M, D, H, B, n):
+        dev = self.dev
+        hid = int(D * self.d.mlp_ratio)
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        return NS(xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * H * n, dt=F32),
+                  x_mid=e(M, D, dt=F32), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
+                  x_out=e(M, D, dt=F32))
+
+    def _scratch(self, M, D, H, B, n):
+        dev = self.dev
+        hid = int(D * self.d.mlp_ratio)
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), dxbA=e(M, D), dxbB=e(M, D), dxln=e(M, D), dh1=e(M, hid), dqkv=e(M, 3 * D),
+                  dao=e(M, D), delta=e(B * H * n, dt=F32))
+
+    def ws(self, B: int, n_vis: Optional[int] = None, N: Optional[int] = None) -> NS:
+        """workspace for batch size B (and visible-token count n_vis); allocated once, reused every step"""
+        d = self.d
+        N = d.num_patches if N is None else N
+        key = (B, n_vis, N)
+        if key in self._ws:
+            return self._ws[key]
+        dev = self.dev
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        w = NS(B=B, N=N, n_vis=n_vis, n_msk=N - n_vis if n_vis is not None else None)
+        if self.enc_prefix is not None:
+            w.clips = e(B, d.in_chans, d.num_frames, d.img_size, d.img_size, dt=F32)
+        w.mask_u8 = torch.zeros(B, N, dtype=torch.uint8, device=dev)
+        w.status = torch.zeros(1, dtype=I32, device=dev)
+        if n_vis is not None:
+            w.vis_idx = torch.zeros(B, n_vis, dtype=I32, device=dev)
+            w.msk_idx = torch.zeros(B, N - n_vis, dtype=I32, device=dev)
+        if self.enc_prefix is not None and n_vis is not None:
+            Me = B * n_vis
+            w.Me = Me
+            w.xp = e(Me, d.patch_dim)
+            w.enc_x0 = e(Me, d.enc_dim, dt=F32)
+            w.enc = [self._block_ws(Me, d.enc_dim, d.enc_heads, B, n_vis) for _ in range(d.enc_depth)]
+            w.enc_out = e(Me, d.enc_dim)
+            w.enc_mean, w.enc_rstd = e(Me, dt=F32), e(Me, dt=F32)
+            w.enc_s = self._scratch(Me, d.enc_dim, d.enc_heads, B, n_vis)
+            w.d_encout = e(Me, d.enc_dim)
+        if self.dec_prefix is not None:
+            Md = B * N
+            w.Md = Md
+            w.x_full = e(B, N, d.dec_dim, dt=F32)
+            w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N) for _ in range(d.dec_depth)]
+            w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N)
+            if n_vis is not None:
+                Mm = B * (N - n_vis)
+                w.Mm = Mm
+                w.dec_ln = e(Mm, d.dec_dim)
+                w.dec_mean, w.dec_rstd = e(Mm, dt=F32), e(Mm, dt=F32)
+                w.pred = e(Mm, d.patch_out)
+                w.dpred = e(Mm, d.patch_out)
+                w.d_decln = e(Mm, d.dec_dim)
+                w.row_loss = e(Mm, dt=F32)
+                w.loss = torch.zeros(1, dtype=F32, device=dev)
+                w.d_e2d = e(B * n_vis, d.dec_dim)
+        self._ws[key] = w
+        return w
+
+    # ------------------------------------------------------------------ inputs
+    def set_inputs(self, w: NS, videos: torch.Tensor, mask: Optional[torch.Tensor]):
+        """H2D / D2D copy of the batch into the persistent input buffers, then mask -> index lists on the device
+        (no host sync: the reference's boolean indexing does a nonzero() round trip, modeling_pretrain.py:90)."""
+        if videos.data_ptr() != w.clips.data_ptr():
+            w.clips.copy_(videos, non_blocking=True)
+        if mask is not None:
+            w.mask_u8.copy_(mask.reshape(w.B, -1), non_blocking=True)
+            ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
+
+    # ------------------------------------------------------------------ transformer block
+    def _block_fwd(self, W, L, x_in, B, n, H):
+        eps, scale = self.d.eps, 64 ** -0.5
+        ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
+        ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse)
+        ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
+        ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
+        ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
+        ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
+        return L.x_out
+
+    def _wgrad(self, dY, X, G):
+        R, P = dY.shape
+        Q = X.shape[1]
+        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=True)
+
+    def _block_bwd(self, W, L, S, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
+        """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in (may alias dx_out)."""
+        scale = 64 ** -0.5
+        D = x_in.shape[1]
+        # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
+        ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, S.dh1, aux=L.h1)
+        self._wgrad(dxb_out, L.g, W.g_fc2)
+        ops.colsum_bf16(dxb_out, W.g_fc2b)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dh1, W.fc1, S.dxln)
+        self._wgrad(S.dh1, L.xln2, W.g_fc1)
+        ops.colsum_bf16(S.dh1, W.g_fc1b)
+        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dx_out, S.dxB, S.dxbB, W.g_ln2w, W.g_ln2b)
+        # attention: x_mid = x_in + proj(attn(LN1(x_in)))
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dxbB, W.proj, S.dao)
+        self._wgrad(S.dxbB, L.ao, W.g_proj)
+        ops.colsum_bf16(S.dxbB, W.g_projb)
+        ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, S.dqkv, S.delta)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dqkv, W.qkv, S.dxln)
+        self._wgrad(S.dqkv, L.xln1, W.g_qkv)
+        ops.colsum_bf16(S.dqkv[:, :D], W.g_qb)
+        ops.colsum_bf16(S.dqkv[:, 2 * D:], W.g_vb)
+        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
+
+    def plan_segments(self, blocks_per_bucket: int = 3) -> List[Tuple[int, int]]:
+        """Contiguous ranges of the flat gradient buffer in the order backward completes them (the data-parallel
+        all-reduce buckets): [decoder + head + e2d + mask_token], then encoder blocks from the top in groups of three
+        (encoder.norm rides with the first group, patch_embed with the last).  Together they tile the buffer."""
+        d, s = self.d, self.store
+        segs: List[List[str]] = []
+        if self.dec_prefix is not None:
+            p = self.dec_prefix
+            names = [p + "head.weight", p + "head.bias", p + "norm.weight", p + "norm.bias"]
+            for W in self.decW:
+                names += W.names
+            if self.top:
+                names += ["encoder_to_decoder.weight", "mask_token"]
+            segs.append(names)
+        if self.enc_prefix is not None:
+            p = self.enc_prefix
+            cur = [p + "norm.weight", p + "norm.bias"]
+            cnt = 0
+            for i in range(d.enc_depth - 1, -1, -1):
+                cur += self.encW[i].names
+                cnt += 1
+                if cnt == blocks_per_bucket and i > 0:
+                    segs.append(cur)
+                    cur, cnt = [], 0
+            cur += [p + "patch_embed.proj.weight", p + "patch_embed.proj.bias"]
+            segs.append(cur)
+        return [s.range_of(n) for n in segs]
+
+    def _seg(self, idx: int):
+        if self.segment_hook is not None:
+            lo, hi = self.segments[idx]
+            self.segment_hook(idx, lo, hi)
+
+    # ------------------------------------------------------------------ encoder
+    def encoder_forward(self, w: NS):
+        """modeling_pretrain.py:83-101 over the VISIBLE tokens only; returns bf16 [B*n_vis, enc_dim] (after encoder.norm)."""
+        d, s, p = self.d, self.store, self.enc_prefix
+        ops.patch_gather(w.clips, d.tubelet, d.patch_size, w.vis_idx, w.xp)
+        ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, w.xp, s.bview(p + "patch_embed.proj.weight"), w.enc_x0,
+                 bias=s.view(p + "patch_embed.proj.bias"), pos=self.pos_enc, row_idx=w.vis_idx.view(-1), rows_in=w.Me, rows_out=w.Me)
+        x = w.enc_x0
+        for W, L in zip(self.encW, w.enc):
+            x = self._block_fwd(W, L, x, w.B, w.n_vis, d.enc_heads)
+        ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.enc_out, w.enc_mean, w.enc_rstd)
+        return w.enc_out
+
+    def encoder_backward(self, w: NS, d_out_bf16: torch.Tensor):
+        d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
+        x_last = w.enc[-1].x_out if w.enc else w.enc_x0
+        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, S.dxA, S.dxbA,
+                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
+        seg = 1 if self.dec_prefix is not None else 0
+        cnt = 0
+        for i in range(d.enc_depth - 1, -1, -1):
+            x_in = w.enc[i - 1].x_out if i > 0 else w.enc_x0
+            self._block_bwd(self.encW[i], w.enc[i], S, x_in, S.dxA, S.dxbA, S.dxA, S.dxbA, w.B, w.n_vis, d.enc_heads)
+            cnt += 1
+            if cnt == 3 and i > 0:  # gradient buckets of three encoder blocks (~85 MB fp32 at ViT-B)
+                self._seg(seg)
+                seg, cnt = seg + 1, 0
+        self._wgrad(S.dxbA, w.xp, s.g2d(p + "patch_embed.proj.weight"))
+        ops.colsum_bf16(S.dxbA, s.gview(p + "patch_embed.proj.bias"))
+        self._seg(seg)
+
+    # ------------------------------------------------------------------ bridge
+    def bridge_forward(self, w: NS, enc_out_bf16: torch.Tensor):
+        """modeling_pretrain.py:256-263: encoder_to_decoder (no bias) + pos for the visible half, mask_token + pos for the rest."""
+        d, s = self.d, self.store
+        ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, enc_out_bf16, s.bview("encoder_to_decoder.weight"), w.x_full.view(w.Md, d.dec_dim),
+                 pos=self.pos_dec, row_idx=w.vis_idx.view(-1), rows_in=w.n_vis, rows_out=w.N, row_off=0)
+        ops.fill_mask_tokens(s.view("mask_token").view(-1), self.pos_dec, w.msk_idx, w.n_vis, w.x_full)
+        return w.x_full
+
+    def bridge_backward(self, w: NS, dx_full: torch.Tensor, enc_out_bf16: torch.Tensor):
+        d, s = self.d, self.store
+        ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, s.gview("mask_token").view(-1))
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, w.d_e2d, s.bview("encoder_to_decoder.weight"), w.d_encout)
+        self._wgrad(w.d_e2d, enc_out_bf16, s.g2d("encoder_to_decoder.weight"))
+        return w.d_encout
+
+    # ------------------------------------------------------------------ decoder
+    def decoder_forward(self, w: NS, x_full: torch.Tensor, n_ret: int):
+        """modeling_pretrain.py:152-161; x_full fp32 [B, N, dec_dim]; returns bf16 predictions [B*n_ret, patch_out]."""
+        d, s, p = self.d, self.store, self.dec_prefix
+        x = x_full.view(w.Md, d.dec_dim)
+        for W, L in zip(self.decW, w.dec):
+            x = self._block_fwd(W, L, x, w.B, w.N, d.dec_heads)
+        ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.dec_ln, w.dec_mean, w.dec_rstd,
+                          rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, w.dec_ln, s.bview(p + "head.weight"), w.pred, bias=s.view(p + "head.bias"))
+        return w.pred
+
+    def decoder_backward(self, w: NS, dpred_bf16: torch.Tensor, x_full: torch.Tensor, n_ret: int):
+        d, s, p, S = self.d, self.store, self.dec_prefix, w.dec_s
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, dpred_bf16, s.bview(p + "head.weight"), w.d_decln)
+        self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"))
+        ops.colsum_bf16(dpred_bf16, s.gview(p + "head.bias"))
+        x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
+        S.dxA.zero_()
+        S.dxbA.zero_()   # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
+        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, S.dxA, S.dxbA,
+                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        for i in range(d.dec_depth - 1, -1, -1):
+            x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
+            self._block_bwd(self.decW[i], w.dec[i], S, x_in, S.dxA, S.dxbA, S.dxA, S.dxbA, w.B, w.N, d.dec_heads)
+        return S.dxA
+
+    # ------------------------------------------------------------------ whole model
+    def forward(self, w: NS):
+        enc_out = self.encoder_forward(w)
+        x_full = self.bridge_forward(w, enc_out)
+        return self.decoder_forward(w, x_full, w.n_msk)
+
+    def loss_forward(self, w: NS, normalize_target: bool = True, grad_scale: float = 1.0):
+        """engine_for_pretraining.py:43-67 fused: target build + MSE + d(loss)/d(pred) in one pass."""
+        d = self.d
+        ops.target_mse(w.clips, d.tubelet, d.patch_size, w.msk_idx, w.pred, normalize_target, grad_scale, w.row_loss, w.loss, w.dpred)
+        return w.loss
+
+    def backward(self, w: NS):
+        dx_full = self.decoder_backward(w, w.dpred, w.x_full, w.n_msk)
+        d_encout = self.bridge_backward(w, dx_full, w.enc_out)
+        self._seg(0)
+        self.encoder_backward(w, d_encout)
+
+    # ------------------------------------------------------------------ optimizer side
+    def grad_norm(self) -> torch.Tensor:
+        """utils.py:376-388: global L2 norm of all gradients; stays on the device."""
+        ops.sumsq_norm(self.store.grads, self.norm_partial, self.norm_out)
+        return self.norm_out

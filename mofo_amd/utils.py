@@ -1,0 +1,253 @@
+"""Drop-in for the parts of the reference's ``utils.py`` that the pretraining path touches: the loss-scaler object
+(utils.py:347-373), the per-iteration cosine schedule (:391-408), meters (:27-170), distributed helpers (:197-296) and
+checkpoint save / auto-resume (:411-472).  Host-side bookkeeping; the numeric parts (gradient norm, clipping, the
+optimizer update) run as HIP kernels on the flat buffers."""
+import datetime
+import glob
+import math
+import os
+import time
+from collections import defaultdict, deque
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+# ----------------------------------------------------------------------------------------------- meters
+class SmoothedValue(object):
+    """utils.py:27-86"""
+
+    def __init__(self, window_size=20, fmt=None):
+        self.deque = deque(maxlen=window_size)
+        self.total = 0.0
+        self.count = 0
+        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+
+    def update(self, value, n=1):
+        self.deque.append(value)
+        self.count += n
+        self.total += value * n
+
+    def synchronize_between_processes(self):
+        """utils.py:45-56: all-reduce (count, total); the window is left local"""
+        if not is_dist_avail_and_initialized():
+            return
+        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        dist.barrier()
+        dist.all_reduce(t)
+        t = t.tolist()
+        self.count = int(t[0])
+        self.total = t[1]
+
+    @property
+    def median(self):
+        return torch.tensor(list(self.deque)).median().item()
+
+    @property
+    def avg(self):
+        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
+
+    @property
+    def global_avg(self):
+        return self.total / self.count
+
+    @property
+    def max(self):
+        return max(self.deque)
+
+    @property
+    def value(self):
+        return self.deque[-1]
+
+    def __str__(self):
+        return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
+
+
+class MetricLogger(object):
+    """utils.py:89-170"""
+
+    def __init__(self, delimiter="\t"):
+        self.meters = defaultdict(SmoothedValue)
+        self.delimiter = delimiter
+
+    def update(self, **kwargs):
+        for k, v in kwargs.items():
+            if v is None:
+                continue
+            if isinstance(v, torch.Tensor):
+                v = v.item()
+            assert isinstance(v, (float, int))
+            self.meters[k].update(v)
+
+    def __getattr__(self, attr):
+        if attr in self.meters:
+            return self.meters[attr]
+        if attr in self.__dict__:
+            return self.__dict__[attr]
+        raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
+
+    def __str__(self):
+        return self.delimiter.join("{}: {}".format(name, str(meter)) for name, meter in self.meters.items())
+
+    def synchronize_between_processes(self):
+        for meter in self.meters.values():
+            meter.synchronize_between_processes()
+
+    def add_meter(self, name, meter):
+        self.meters[name] = meter
+
+    def log_every(self, iterable, print_freq, header=None):
+        i = 0
+        header = header or ''
+        start_time = time.time()
+        end = time.time()
+        iter_time = SmoothedValue(fmt='{avg:.4f}')
+        data_time = SmoothedValue(fmt='{avg:.4f}')
+        n = len(iterable)
+        space_fmt = ':' + str(len(str(n))) + 'd'
+        log_msg = self.delimiter.join([header, '[{0' + space_fmt + '}/{1}]', 'eta: {eta}', '{meters}', 'time: {time}', 'data: {data}'])
+        for obj in iterable:
+            data_time.update(time.time() - end)
+            yield obj
+            iter_time.update(time.time() - end)
+            if i % print_freq == 0 or i == n - 1:
+                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
+                print(log_msg.format(i, n, eta=eta, meters=str(self), time=str(iter_time), data=str(data_time)))
+            i += 1
+            end = time.time()
+        total = time.time() - start_time
+        print('{} Total time: {} ({:.4f} s / it)'.format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+
+
+# ----------------------------------------------------------------------------------------------- distributed
+def is_dist_avail_and_initialized():
+    return dist.is_available() and dist.is_initialized()
+
+
+def get_world_size():
+    return dist.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return dist.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def init_distributed_mode(args):
+    """utils.py:255-296, env:// launch (torch.distributed.run / launch): one process per GPU, backend 'nccl' = RCCL."""
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:
+        args.rank = int(os.environ["RANK"])
+        args.world_size = int(os.environ['WORLD_SIZE'])
+        args.gpu = int(os.environ.get('LOCAL_RANK', 0))
+    else:
+        args.distributed = False
+        return
+    args.distributed = True
+    backend = getattr(args, "dist_backend", None) or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(args.gpu)
+    args.dist_backend = backend
+    dist.init_process_group(backend=backend, init_method=getattr(args, "dist_url", "env://"), world_size=args.world_size, rank=args.rank)
+    dist.barrier()
+
+
+# ----------------------------------------------------------------------------------------------- scaler / norms
+class NativeScalerWithGradNormCount:
+    """utils.py:347-373.  The reference wraps torch.cuda.amp.GradScaler for fp16; this path computes in bf16 with fp32
+    accumulation, so the scale is the constant 1.0 -- the call contract (backward -> norm or clip -> optimizer step,
+    returns the norm; ``state_dict()['scale']``) is what the engine relies on (engine_for_pretraining.py:175-177)."""
+    state_dict_key = "amp_scaler"
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        if create_graph:
+            raise NotImplementedError("second-order optimizers are not on the pretraining path")
+        loss.backward()
+        if not update_grad:
+            return None
+        model = getattr(optimizer, "model", None)
+        if model is None:
+            raise TypeError("use mofo_amd.optim_factory.create_optimizer: the fused step works on the model's flat buffers")
+        sync = getattr(model, "_grad_sync", None)
+        if sync is not None:
+            sync.finish()              # data-parallel all-reduces launched during backward
+        norm = model.runtime().grad_norm()     # utils.py:376-388, device scalar
+        optimizer.step(grad_norm=norm, max_norm=clip_grad if clip_grad else 0.0)
+        return norm
+
+    def state_dict(self):
+        return {"scale": 1.0}
+
+    def load_state_dict(self, state_dict):
+        pass
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
+    """utils.py:376-388 on arbitrary parameter lists (torch ops; the engine uses the fused flat-buffer norm instead)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad.detach() for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.)
+    if norm_type == math.inf:
+        return max(g.abs().max() for g in grads)
+    return torch.norm(torch.stack([torch.norm(g, norm_type) for g in grads]), norm_type)
+
+
+def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
+    """utils.py:391-408"""
+    warmup_schedule = np.array([])
+    warmup_iters = warmup_epochs * niter_per_ep
+    if warmup_steps > 0:
+        warmup_iters = warmup_steps
+    print("Set warmup steps = %d" % warmup_iters)
+    if warmup_epochs > 0:
+        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
+    n = epochs * niter_per_ep - warmup_iters
+    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)])
+    schedule = np.concatenate((warmup_schedule, schedule))
+    assert len(schedule) == epochs * niter_per_ep
+    return schedule
+
+
+# ----------------------------------------------------------------------------------------------- checkpoints
+def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """utils.py:411-433: output_dir/checkpoint-{epoch}.pth = {'model','optimizer','epoch','scaler','args'} from rank 0.
+    'model' uses the reference's state_dict names/shapes, so the reference's fine-tuning loader reads it."""
+    if loss_scaler is None:
+        raise NotImplementedError("deepspeed checkpoints belong to fine-tuning (out of scope)")
+    path = os.path.join(args.output_dir, 'checkpoint-%s.pth' % str(epoch))
+    save_on_master({'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+                    'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': args}, path)
+
+
+def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
+    """utils.py:436-472: pick the highest checkpoint-*.pth in output_dir when auto_resume, restore model/optimizer/epoch."""
+    if getattr(args, "auto_resume", False) and not getattr(args, "resume", ""):
+        best = -1
+        for ckpt in glob.glob(os.path.join(args.output_dir, 'checkpoint-*.pth')):
+            t = ckpt.split('-')[-1].split('.')[0]
+            if t.isdigit():
+                best = max(int(t), best)
+        if best >= 0:
+            args.resume = os.path.join(args.output_dir, 'checkpoint-%d.pth' % best)
+        print("Auto resume checkpoint: %s" % getattr(args, "resume", ""))
+    if getattr(args, "resume", ""):
+        checkpoint = torch.load(args.resume, map_location='cpu', weights_only=False)
+        model_without_ddp.load_state_dict(checkpoint['model'])
+        print("Resume checkpoint %s" % args.resume)
+        if 'optimizer' in checkpoint and 'epoch' in checkpoint:
+            optimizer.load_state_dict(checkpoint['optimizer'])
+            args.start_epoch = checkpoint['epoch'] + 1
+            if 'scaler' in checkpoint:
+                loss_scaler.load_state_dict(checkpoint['scaler'])
+            print("With optim & sched!")
