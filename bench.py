@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""Headline benchmark: clips/sec of the ViT-B masked-video-autoencoder PRETRAINING step (16x3x224x224 clips, tube mask
+90 %, decoder depth 4) on N MI355X GPUs of one node -- BASELINE.json's metric on BASELINE.json configs[1] (N=1) / [2] (N=8).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One step = what the reference's train_one_epoch does per batch (engine_for_pretraining.py:29-69,168-179) minus its PNG
+dump: lr/wd schedule write, target build + forward + MSE (fused), loss read-back + finite check, zero_grad, backward,
+gradient all-reduce (N>1, overlapped), global grad norm, AdamW, device sync.  Inputs are synthetic, generated straight
+into the model's device input buffers before the timed region.  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+STEP_FLOP_PER_CLIP = 202.3e9   # algorithmic training-step FLOPs per clip (ViT-B, dec 4, mask 0.9)
+PEAK_BF16 = 2.5e15             # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
+PEAK_HBM = 8.0e12              # spec HBM3E bandwidth
+
+
+class _Args:
+    opt = "adamw"
+    lr = 1.5e-4
+    weight_decay = 0.05
+    opt_eps = 1e-8
+    opt_betas = (0.9, 0.95)
+
+
+def cpu_baseline(seconds_budget: float):
+    """The oracle (fp32 CPU restatement of the reference step, pinned to the reference's fixtures) timed on this box's
+    host cores on a bounded sample: ViT-B, batch 2 (BASELINE config[0] shapes), one warm-up step + timed steps."""
+    from oracle import pretrain_oracle as O
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    print(f"[bench] cpu baseline on {cores} host threads ...", file=sys.stderr, flush=True)
+    cfg = O.VIT_B
+    P = O.keyed_params(cfg, "xavier")
+    x = O.keyed_clips(2, cfg)
+    np.random.seed(0)
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.9) for _ in range(2)])).bool()
+    st = O.AdamWState()
+    O.train_step(x, mask, P, cfg, st)          # warm-up (allocations, thread pool)
+    t0 = time.time()
+    n = 0
+    while True:
+        O.train_step(x, mask, P, cfg, st)
+        n += 1
+        print(f"[bench] cpu baseline step {n}: {time.time() - t0:.1f} s", file=sys.stderr, flush=True)
+        if time.time() - t0 > seconds_budget or n >= 8:
+            break
+    dt = time.time() - t0
+    return {"value": round(2 * n / dt, 4), "unit": "clips/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fp32 torch-CPU train step, ViT-B dec4, batch 2, {n} timed steps after 1 warm-up ({dt:.1f} s)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE configs[1]/[2]: 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing (roofline block)")
+    ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+
+    from mofo_amd import _lib, optim_factory, utils
+    from mofo_amd import modeling_pretrain as mp
+    from mofo_amd.dist import DataParallel
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+
+    torch.manual_seed(0)           # identical random-init replica on every rank (DDP would broadcast rank 0's)
+    model = mp.pretrain_videomae_base_patch16_224(decoder_depth=4).to(dev)
+    B, N, n_vis = args.batch, 1568, 160
+    clips, mask_u8 = model.input_buffers(B, n_vis)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # seed = base + rank, run_mae_pretraining.py:166
+    clips.normal_(generator=gen)
+    np.random.seed(rank)
+    mgen = TubeMaskingGenerator((8, 14, 14), 0.9)
+    mask_u8.copy_(torch.from_numpy(np.stack([mgen() for _ in range(B)]).astype(np.uint8)))
+    mask_dev = mask_u8.clone()
+    _Args.lr = 1.5e-4 * (B * world) / 256                          # run_mae_pretraining.py:217
+    opt = optim_factory.create_optimizer(_Args, model)
+    wrapped = DataParallel(model) if world > 1 else model
+    scaler = utils.NativeScalerWithGradNormCount()
+    total_steps = args.steps + args.warmup
+    lr_sched = utils_quiet(utils.cosine_scheduler, _Args.lr, 1e-5, 1, total_steps + 1, warmup_epochs=0)
+    wd_sched = utils_quiet(utils.cosine_scheduler, 0.05, 0.05, 1, total_steps + 1)
+
+    def step(it):
+        for g in opt.param_groups:
+            g["lr"] = lr_sched[it] * g["lr_scale"]
+            if g["weight_decay"] > 0:
+                g["weight_decay"] = wd_sched[it]
+        loss = wrapped.forward_loss(clips, mask_dev, True)
+        lv = loss.item()                                            # engine_for_pretraining.py:69 (sync #1)
+        if not math.isfinite(lv):
+            raise SystemExit(f"loss is {lv}")
+        opt.zero_grad()
+        scaler(loss, opt, clip_grad=None)
+        torch.cuda.synchronize()                                    # engine_for_pretraining.py:179 (sync #2)
+        return lv
+
+    for it in range(args.warmup):
+        step(it)
+    model.check_status()
+    prof = None
+    if not args.no_kernel_events:
+        prof = _lib.EventProfiler()
+        _lib.PROFILER = prof
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for it in range(args.steps):
+        last = step(args.warmup + it)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    _lib.PROFILER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    clips_per_s = B * world * args.steps / dt
+
+    out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "ViT-B (enc 12x768, dec 4x384) 16x224x224 tube mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
+                                  "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
+                      "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "final_loss": round(last, 5),
+                      "step_mfma_frac": round(clips_per_s / world * STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}}
+
+    if prof is not None:
+        summ = prof.summary()
+        names = {("gemm", 0, 0): "gemm_nt_bf16", ("gemm", 0, 1): "gemm_nt_bias_gelu", ("gemm", 0, 2): "gemm_nt_resid_f32",
+                 ("gemm", 0, 3): "gemm_nt_pos_f32", ("gemm", 1, 0): "gemm_nn_bf16", ("gemm", 1, 4): "gemm_nn_dgelu",
+                 ("gemm", 2, 5): "gemm_tn_wgrad_f32"}
+        mfma_keys = [k for k in summ if k[0] in ("gemm", "attn_fwd", "attn_bwd")]
+        total_ms = sum(v["ms"] for v in summ.values())
+        dom = max(summ, key=lambda k: summ[k]["ms"])
+        d = summ[dom]
+        is_mfma = dom in mfma_keys
+        ach = d["work"] / (d["ms"] * 1e-3)
+        out["roofline"] = {"kernel": names.get(dom, "_".join(str(x) for x in dom)), "bound": "mfma" if is_mfma else "hbm",
+                           "achieved": round(ach / (1e12 if is_mfma else 1e9), 2), "peak": (PEAK_BF16 / 1e12) if is_mfma else (PEAK_HBM / 1e9),
+                           "unit": "TFLOP/s" if is_mfma else "GB/s", "frac": round(ach / (PEAK_BF16 if is_mfma else PEAK_HBM), 4),
+                           "traffic": None, "launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
+                           "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
+        gem = [summ[k] for k in summ if k[0] == "gemm"]
+        if gem:
+            out["roofline"]["all_gemm_tflops"] = round(sum(g["work"] for g in gem) / sum(g["ms"] for g in gem) / 1e9, 2)
+        if args.breakdown and rank == 0:
+            print(f"{'kernel class':28s} {'launches':>8s} {'ms/step':>9s} {'share':>6s} {'rate':>12s}", file=sys.stderr)
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1]["ms"]):
+                rate = v["work"] / (v["ms"] * 1e-3)
+                unit = "TF/s" if k in mfma_keys else "GB/s"
+                print(f"{names.get(k, '_'.join(str(x) for x in k)):28s} {v['launches'] // args.steps:8d} {v['ms'] / args.steps:9.3f} "
+                      f"{v['ms'] / total_ms:6.1%} {rate / (1e12 if k in mfma_keys else 1e9):9.1f} {unit}", file=sys.stderr)
+            print(f"sum of kernel time {total_ms / args.steps:.3f} ms/step vs wall {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)
+
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def host_cores() -> int:
+    """threads this process may really use: affinity mask, cgroup cpu quota, and the GPU box's 16-core share per GPU"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16))
+
+
+def utils_quiet(fn, *a, **k):
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+if __name__ == "__main__":
+    main()

@@ -67,6 +67,39 @@ def load():
     return _lib
 
 
+class EventProfiler:
+    """Per-kernel-class timing with HIP events recorded on the launch stream (torch's current stream), used by bench.py.
+    ``begin(key, work)`` / ``end()`` bracket one C-ABI call; ``summary()`` joins after a device synchronize."""
+
+    def __init__(self):
+        self.records = []   # (key, work, start_event, end_event)
+        self._cur = None
+
+    def begin(self, key, work=0.0):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._cur = (key, work, e0)
+
+    def end(self):
+        key, work, e0 = self._cur
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((key, work, e0, e1))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for key, work, e0, e1 in self.records:
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+PROFILER = None   # set to an EventProfiler by bench.py
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = load().mofo_last_error().decode(errors="replace")

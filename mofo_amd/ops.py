@@ -41,6 +41,18 @@ def _p(t):
     return 0 if t is None else t.data_ptr()
 
 
+def _run(name, key, work, *args):
+    """one C-ABI call on the current stream; optionally bracketed by HIP events (bench.py's per-kernel timing)"""
+    fn = getattr(_lib.load(), name)
+    prof = _lib.PROFILER
+    if prof is None:
+        _lib.check(fn(*args, _stream()), name)
+    else:
+        prof.begin(key, work)
+        _lib.check(fn(*args, _stream()), name)
+        prof.end()
+
+
 def gemm(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
          row_off=0, splits=1, accumulate=False):
     """C = epilogue(A (op) B).  A, B bf16 2-D; see include/mofo_hip.h for op / epilogue semantics."""
@@ -89,7 +101,7 @@ def gemm(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=Non
                  ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
                  rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0)
-    _lib.check(_lib.load().mofo_gemm(C.byref(a), _stream()), "mofo_gemm")
+    _run("mofo_gemm", ("gemm", op, epi), 2.0 * M * N * K, C.byref(a))
     return C_
 
 
@@ -97,7 +109,7 @@ def colsum_bf16(X, out):
     _chk(X, BF16, "X", 2), _chk(out, F32, "out", 1)
     if out.numel() != X.shape[1]:
         raise ValueError("out must have N entries")
-    _lib.check(_lib.load().mofo_colsum_bf16(_p(X), _ld(X), X.shape[0], X.shape[1], _p(out), _stream()), "mofo_colsum_bf16")
+    _run("mofo_colsum_bf16", ("colsum",), 2.0 * X.shape[0] * X.shape[1], _p(X), _ld(X), X.shape[0], X.shape[1], _p(out))
     return out
 
 
@@ -111,8 +123,8 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
         raise ValueError("layernorm_fwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_fwd: row map exceeds x")
-    _lib.check(_lib.load().mofo_layernorm_fwd(_p(x), _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off, _p(y), _ld(y),
-                                              _p(mean), _p(rstd), _stream()), "mofo_layernorm_fwd")
+    _run("mofo_layernorm_fwd", ("ln_fwd",), 6.0 * M * D, _p(x), _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off, _p(y), _ld(y),
+         _p(mean), _p(rstd))
     return y
 
 
@@ -134,18 +146,16 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         raise ValueError("layernorm_bwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_bwd: row map exceeds x")
-    _lib.check(_lib.load().mofo_layernorm_bwd(_p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres),
-                                              _ld(dres) if dres is not None else 0, M, D, rows_in, rows_out, row_off,
-                                              _p(dx), _ld(dx), _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
-                                              _stream()), "mofo_layernorm_bwd")
+    _run("mofo_layernorm_bwd", ("ln_bwd",), (6.0 + (4.0 if dres is not None else 0.0) + 4.0 + (2.0 if dxb is not None else 0.0)) * M * D,
+         _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _ld(dres) if dres is not None else 0, M, D,
+         rows_in, rows_out, row_off, _p(dx), _ld(dx), _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db))
 
 
 def attention_fwd(qkv, B, N, H, scale, out, lse2):
     _chk(qkv, BF16, "qkv", 2), _chk(out, BF16, "out", 2), _chk(lse2, F32, "lse2")
     if qkv.shape != (B * N, 3 * H * 64) or out.shape != (B * N, H * 64) or lse2.numel() != B * H * N:
         raise ValueError("attention_fwd: shape mismatch")
-    _lib.check(_lib.load().mofo_attention_fwd(_p(qkv), _ld(qkv), B, N, H, scale, _p(out), _ld(out), _p(lse2), _stream()),
-               "mofo_attention_fwd")
+    _run("mofo_attention_fwd", ("attn_fwd",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, _p(out), _ld(out), _p(lse2))
     return out
 
 
@@ -155,8 +165,8 @@ def attention_bwd(qkv, out, dout, lse2, B, N, H, scale, dqkv, delta):
     if (qkv.shape != (B * N, 3 * H * 64) or dqkv.shape != qkv.shape or out.shape != (B * N, H * 64) or dout.shape != out.shape
             or lse2.numel() != B * H * N or delta.numel() != B * H * N):
         raise ValueError("attention_bwd: shape mismatch")
-    _lib.check(_lib.load().mofo_attention_bwd(_p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout), _p(lse2), B, N, H, scale,
-                                              _p(dqkv), _ld(dqkv), _p(delta), _stream()), "mofo_attention_bwd")
+    _run("mofo_attention_bwd", ("attn_bwd",), 8.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout),
+         _p(lse2), B, N, H, scale, _p(dqkv), _ld(dqkv), _p(delta))
     return dqkv
 
 
@@ -165,8 +175,7 @@ def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
     B, N = mask_u8.shape
     if not mask_u8.is_contiguous() or vis_idx.shape != (B, n_vis) or msk_idx.shape != (B, N - n_vis):
         raise ValueError("mask_to_indices: shape mismatch")
-    _lib.check(_lib.load().mofo_mask_to_indices(_p(mask_u8), B, N, n_vis, _p(vis_idx), _p(msk_idx), _p(status), _stream()),
-               "mofo_mask_to_indices")
+    _run("mofo_mask_to_indices", ("mask_idx",), 5.0 * B * N, _p(mask_u8), B, N, n_vis, _p(vis_idx), _p(msk_idx), _p(status))
 
 
 def patch_gather(clips, pt, p, tok_idx, out):
@@ -177,8 +186,8 @@ def patch_gather(clips, pt, p, tok_idx, out):
     n_tok = tok_idx.shape[1]
     if out.shape != (B * n_tok, Cc * pt * p * p):
         raise ValueError("patch_gather: out shape")
-    _lib.check(_lib.load().mofo_patch_gather(_p(clips), B, Cc, T, H, W, pt, p, _p(tok_idx), n_tok, _p(out), _ld(out), _stream()),
-               "mofo_patch_gather")
+    _run("mofo_patch_gather", ("patch_gather",), 6.0 * B * n_tok * Cc * pt * p * p, _p(clips), B, Cc, T, H, W, pt, p, _p(tok_idx), n_tok,
+         _p(out), _ld(out))
     return out
 
 
@@ -187,8 +196,7 @@ def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
     B, N, D = x_full.shape
     if not x_full.is_contiguous() or mask_token.numel() != D or pos.shape[1] != D or msk_idx.shape != (B, N - n_vis) or pos.shape[0] < N:
         raise ValueError("fill_mask_tokens: shape mismatch")
-    _lib.check(_lib.load().mofo_fill_mask_tokens(_p(mask_token), _p(pos), _ld(pos), _p(msk_idx), B, N, n_vis, D, _p(x_full), _stream()),
-               "mofo_fill_mask_tokens")
+    _run("mofo_fill_mask_tokens", ("fill_mask",), 8.0 * B * (N - n_vis) * D, _p(mask_token), _p(pos), _ld(pos), _p(msk_idx), B, N, n_vis, D, _p(x_full))
 
 
 def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
@@ -196,7 +204,7 @@ def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
     B, N, D = dx_full.shape
     if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or d_mask_token.numel() != D:
         raise ValueError("assemble_bwd: shape mismatch")
-    _lib.check(_lib.load().mofo_assemble_bwd(_p(dx_full), B, N, n_vis, D, _p(d_e2d), _p(d_mask_token), _stream()), "mofo_assemble_bwd")
+    _run("mofo_assemble_bwd", ("assemble_bwd",), 4.0 * B * N * D, _p(dx_full), B, N, n_vis, D, _p(d_e2d), _p(d_mask_token))
 
 
 def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, loss, dpred=None, target_out=None):
@@ -214,9 +222,9 @@ def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, los
         _chk(target_out, F32, "target_out", 2)
         if target_out.shape != pred.shape or not target_out.is_contiguous():
             raise ValueError("target_out shape")
-    _lib.check(_lib.load().mofo_target_mse(_p(clips), B, Cc, T, H, W, pt, p, _p(msk_idx), n_msk, _p(pred), _ld(pred),
-                                           1 if normalize else 0, grad_scale, _p(row_loss), _p(loss), _p(dpred),
-                                           _ld(dpred) if dpred is not None else 0, _p(target_out), _stream()), "mofo_target_mse")
+    _run("mofo_target_mse", ("target_mse",), (4.0 + 2.0 + (2.0 if dpred is not None else 0.0)) * B * n_msk * L, _p(clips), B, Cc, T, H, W, pt, p,
+         _p(msk_idx), n_msk, _p(pred), _ld(pred), 1 if normalize else 0, grad_scale, _p(row_loss), _p(loss), _p(dpred),
+         _ld(dpred) if dpred is not None else 0, _p(target_out))
     return loss
 
 
@@ -224,7 +232,7 @@ def sumsq_norm(g, partial, out_norm):
     _chk(g, F32, "g", 1), _chk(partial, F32, "partial", 1), _chk(out_norm, F32, "out_norm")
     if partial.numel() < 1024:
         raise ValueError("partial must hold 1024 floats")
-    _lib.check(_lib.load().mofo_sumsq(_p(g), g.numel(), _p(partial), _p(out_norm), _stream()), "mofo_sumsq")
+    _run("mofo_sumsq", ("sumsq",), 4.0 * g.numel(), _p(g), g.numel(), _p(partial), _p(out_norm))
     return out_norm
 
 
@@ -239,13 +247,13 @@ def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps
         _chk(p_bf16, BF16, "p_bf16", 1)
         if p_bf16.numel() != n:
             raise ValueError("p_bf16 length")
-    _lib.check(_lib.load().mofo_adamw(_p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group), lr0, wd0, lr1, wd1, beta1, beta2,
-                                      eps, step, _p(grad_norm), max_norm, grad_mult, _stream()), "mofo_adamw")
+    _run("mofo_adamw", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
+         lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult)
 
 
 def cast_bf16(src, dst):
     _chk(src, F32, "src", 1), _chk(dst, BF16, "dst", 1)
     if src.numel() != dst.numel():
         raise ValueError("cast_bf16: length mismatch")
-    _lib.check(_lib.load().mofo_cast_bf16(_p(src), _p(dst), src.numel(), _stream()), "mofo_cast_bf16")
+    _run("mofo_cast_bf16", ("cast",), 6.0 * src.numel(), _p(src), _p(dst), src.numel())
     return dst
