@@ -53,6 +53,8 @@ typedef struct mofo_gemm_args {
     int accumulate;               /* F32 epilogue: add into C instead of overwrite */
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
+/* up to 4 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of a transformer block) */
+int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */
 int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* stream);   /* out must be zeroed */

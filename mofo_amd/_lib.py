@@ -30,6 +30,7 @@ _SIGS = {
     "mofo_version": (_i, []),
     "mofo_last_error": (C.c_char_p, []),
     "mofo_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
+    "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
@@ -71,16 +72,22 @@ class EventProfiler:
     """Per-kernel-class timing with HIP events recorded on the launch stream (torch's current stream), used by bench.py.
     ``begin(key, work)`` / ``end()`` bracket one C-ABI call; ``summary()`` joins after a device synchronize."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []   # (key, work, start_event, end_event)
         self._cur = None
+        self.only = only    # bracket just this kernel class (each event costs ~5 us of host time)
 
     def begin(self, key, work=0.0):
+        if self.only is not None and key != self.only:
+            self._cur = None
+            return
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record()
         self._cur = (key, work, e0)
 
     def end(self):
+        if self._cur is None:
+            return
         key, work, e0 = self._cur
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
@@ -98,6 +105,7 @@ class EventProfiler:
 
 
 PROFILER = None   # set to an EventProfiler by bench.py
+RECORDER = None   # a list while the runtime records a launch sequence (ops._run / ops.host_op append to it)
 
 
 def check(rc, what=""):

@@ -64,12 +64,27 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// exact-erf GELU and its derivative (nn.GELU() default)
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GELU and its derivative (nn.GELU() default, modeling_finetune.py:35).  erf is evaluated with the
+// Abramowitz-Stegun 7.1.26 rational form (|error| <= 1.5e-7, far below the bf16 rounding of the result): one v_exp,
+// one v_rcp and five FMAs instead of libm's erff -- the GELU epilogues were VALU-bound on erff.  The same
+// exp(-x^2/2) serves the Gaussian pdf of the derivative.
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& e) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // exp(-x^2/2)
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
+    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
+    const float erf_abs = 1.0f - poly * e;
+    cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return x * cdf;
+}
 __device__ __forceinline__ float dgelu_erf(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
-    const float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
-    return cdf + x * pdf;
+    float cdf, e;
+    gelu_parts(x, cdf, e);
+    return cdf + x * 0.39894228040143268f * e;
 }
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }

@@ -13,7 +13,15 @@
 //       transpose read) fragment reads are bank-conflict free.
 //   LDS-DMA writes are lane-linear, so both swizzles are applied to the per-lane SOURCE address.
 // The MFMA is issued as mfma(Bfrag, Afrag) so that a lane ends up holding 4 CONSECUTIVE n of one m:
-//   acc[mt][nt][j] = C[m0 + 16 mt + (lane & 15)][n0 + 16 nt + 4 (lane >> 4) + j]   (8-B bf16 / 16-B f32 stores)
+//   acc[mt][nt][j] = C[m0 + 16 mt + (lane & 15)][n0 + 16 nt + 4 (lane >> 4) + j]
+// EPILOGUE: the fragment layout touches 16 different rows per store instruction (32-B pieces), which made the short-K
+// GEMMs of the decoder bound by the store path (~1.6 TB/s).  Every epilogue therefore stages the wave's 64x64 f32 tile
+// through LDS (free after the main loop; float4 slot c4 of row r at c4 ^ (r & 15), conflict-free) and then reads /
+// writes global memory in whole row segments: 16 B per lane, 8 rows x 128 B (bf16) or 4 rows x 256 B (f32) per
+// wave-instruction; bias / residual / pre-activation operands are read the same way.
+// GROUPED launches: up to MAXG problems of one (op, epilogue) kind in ONE grid (blockIdx -> problem by a prefix table);
+// the four weight-gradient GEMMs of a transformer block are issued together so that 108+36+144+144 tiles fill 256 CUs
+// without split-K (every split costs another f32 atomic pass over the gradient).
 #include "common.h"
 #include "../../include/mofo_hip.h"
 
@@ -34,6 +42,13 @@ struct GemmP {
     int rows_in, rows_out, row_off;
     int k_per_split;
     int atomic;
+};
+
+constexpr int MAXG = 4;
+struct GroupP {
+    GemmP p[MAXG];
+    int start[MAXG + 1];   // first block of each problem; start[count] = grid size
+    int count;
 };
 
 __device__ __forceinline__ int col_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
@@ -90,22 +105,30 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
 }
 
 template <int LA, int LB, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
+__global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < MAXG; ++k)
+        if (k < G.count && (int)blockIdx.x >= G.start[k]) gi = k;
+    const GemmP p = G.p[gi];
 
     // XCD-aware remap (8 XCDs, private L2s): blocks b and b+8 share an XCD, so give each XCD a contiguous
     // run of tiles with n fastest; the B panel (weights) and one A row-panel then stay L2-resident per XCD.
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int nwg = gridDim.x;
-    int wg = blockIdx.x;
+    const int tiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int nwg = G.start[gi + 1] - G.start[gi];
+    int wg = blockIdx.x - G.start[gi];
     {
         const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
         wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
     }
+    const int split = wg / tiles;
+    wg -= split * tiles;
     const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
-    const int kbeg = blockIdx.z * p.k_per_split;
+    const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -147,77 +170,101 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmP p) {
         cur ^= 1;
     }
 
-    // ------------------------------------------------------------------ epilogue
+    // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
+    float* ep = (float*)smem + wave * 4096;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + 16 * i + (lane & 15);
-        if (m >= p.M) continue;
-        int orow = m;
-        const float* posrow = nullptr;
-        if constexpr (EPI == MOFO_EPI_POS_F32) {
-            orow = (m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
-            posrow = p.pos + (size_t)p.row_idx[m] * p.ldpos;
-        }
+        const int r = 16 * i + (lane & 15);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + 16 * j + 4 * (lane >> 4);
-            if (n >= p.N) continue;
-            f32x4 v = acc[i][j];
-            if constexpr (EPI != MOFO_EPI_F32) {
-                if (p.bias) {
-                    const f32x4 b = *(const f32x4*)(p.bias + n);
-                    v += b;
-                }
-            }
-            if constexpr (EPI == MOFO_EPI_BF16) {
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
-            } else if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
-                u32x2 g = {pack_bf16x2(gelu_erf(v[0]), gelu_erf(v[1])), pack_bf16x2(gelu_erf(v[2]), gelu_erf(v[3]))};
-                *(u32x2*)((bf16_t*)p.C2 + (size_t)orow * p.ldc2 + n) = g;
-            } else if constexpr (EPI == MOFO_EPI_RESID_F32) {
-                const f32x4 r = *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
-                v += r;
-                *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
-            } else if constexpr (EPI == MOFO_EPI_POS_F32) {
-                const f32x4 r = *(const f32x4*)(posrow + n);
-                v += r;
-                *(f32x4*)((float*)p.C + (size_t)orow * p.ldc + n) = v;
-            } else if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
-                const u32x2 h = *(const u32x2*)(p.aux + (size_t)m * p.ldaux + n);
-                v[0] *= dgelu_erf(bf16lo_to_f32(h[0]));
-                v[1] *= dgelu_erf(bf16hi_to_f32(h[0]));
-                v[2] *= dgelu_erf(bf16lo_to_f32(h[1]));
-                v[3] *= dgelu_erf(bf16hi_to_f32(h[1]));
-                u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)((bf16_t*)p.C + (size_t)orow * p.ldc + n) = o;
-            } else {  // MOFO_EPI_F32
-                float* dst = (float*)p.C + (size_t)orow * p.ldc + n;
-                if (p.atomic) {
+            const int c4 = 4 * j + (lane >> 4);
+            *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
+        }
+    }
+    __syncthreads();
+    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
+    if constexpr (OUT_BF16) {
+        const int cg = lane & 7;
+        const int n = nb + cg * 8;
+        if (n >= p.N) return;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            b0 = *(const f32x4*)(p.bias + n);
+            b1 = *(const f32x4*)(p.bias + n + 4);
+        }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) atomicAdd(dst + e, v[e]);
-                } else {
-                    *(f32x4*)dst = v;
-                }
+        for (int it = 0; it < 8; ++it) {
+            const int r = it * 8 + (lane >> 3);
+            const int m = mb + r;
+            if (m >= p.M) continue;
+            f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
+            f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
+            v0 += b0;
+            v1 += b1;
+            if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+                const u32x4 h = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                v0[0] *= dgelu_erf(bf16lo_to_f32(h[0])); v0[1] *= dgelu_erf(bf16hi_to_f32(h[0]));
+                v0[2] *= dgelu_erf(bf16lo_to_f32(h[1])); v0[3] *= dgelu_erf(bf16hi_to_f32(h[1]));
+                v1[0] *= dgelu_erf(bf16lo_to_f32(h[2])); v1[1] *= dgelu_erf(bf16hi_to_f32(h[2]));
+                v1[2] *= dgelu_erf(bf16lo_to_f32(h[3])); v1[3] *= dgelu_erf(bf16hi_to_f32(h[3]));
             }
+            const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+            *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
+                const u32x4 g = {pack_bf16x2(gelu_erf(v0[0]), gelu_erf(v0[1])), pack_bf16x2(gelu_erf(v0[2]), gelu_erf(v0[3])),
+                                 pack_bf16x2(gelu_erf(v1[0]), gelu_erf(v1[1])), pack_bf16x2(gelu_erf(v1[2]), gelu_erf(v1[3]))};
+                *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
+            }
+        }
+    } else {
+        if (EPI == MOFO_EPI_F32 && p.atomic) {
+            // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
+            const int n = nb + lane;
+            if (n >= p.N) return;
+            float* dst = (float*)p.C + (size_t)mb * p.ldc + n;
+            const int rows = min(64, p.M - mb);
+            for (int r = 0; r < rows; ++r) {
+                atomicAdd(dst, ep[r * 64 + ((((lane >> 2) ^ (r & 15)) << 2) | (lane & 3))]);
+                dst += p.ldc;
+            }
+            return;
+        }
+        const int c4 = lane & 15;
+        const int n = nb + c4 * 4;
+        if (n >= p.N) return;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int r = it * 4 + (lane >> 4);
+            const int m = mb + r;
+            if (m >= p.M) continue;
+            f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
+            v += bv;
+            size_t orow = m;
+            if constexpr (EPI == MOFO_EPI_RESID_F32) {
+                v += *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+            } else if constexpr (EPI == MOFO_EPI_POS_F32) {
+                orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
+                v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
+            }
+            *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
         }
     }
 }
 
 template <int LA, int LB, int EPI>
-int launch(const GemmP& p, int splits, hipStream_t s) {
-    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI>), dim3(tiles, 1, splits), dim3(256), 0, s, p);
+int launch(const GroupP& g, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI>), dim3(g.start[g.count]), dim3(256), 0, s, g);
     MOFO_CHECK_LAUNCH("mofo_gemm");
     return MOFO_OK;
 }
 
 }  // namespace
 
-extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
-    if (!a || !a->A || !a->B || !a->C) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null operand");
+static int fill_problem(const mofo_gemm_args* a, GemmP& p, int& blocks) {
+    if (!a->A || !a->B || !a->C) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: non-positive dims %d %d %d", a->M, a->N, a->K);
     const int op = a->op, epi = a->epilogue;
     // alignment / divisibility the kernels are built for
@@ -225,27 +272,29 @@ extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
     if (op == MOFO_GEMM_NT && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_NN && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NN: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_TN && a->M % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm TN: M=%d must be a multiple of 8", a->M);
-    if (a->ldc % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: ldc must be a multiple of 4");
+    const bool out_bf16 = (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_DGELU_BF16);
+    if (a->ldc % (out_bf16 ? 8 : 4)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: ldc must be a multiple of %d", out_bf16 ? 8 : 4);
     int splits = a->splits < 1 ? 1 : a->splits;
     if (splits > 1 && epi != MOFO_EPI_F32) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: split-K only with the f32 accumulate epilogue");
-    if (epi == MOFO_EPI_BIAS_GELU && !a->C2) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: BIAS_GELU needs C2");
-    if (epi == MOFO_EPI_RESID_F32 && !a->resid) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_F32 needs resid");
-    if (epi == MOFO_EPI_DGELU_BF16 && !a->aux) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: DGELU needs aux");
-    if (epi == MOFO_EPI_POS_F32 && (!a->pos || !a->row_idx || a->rows_in <= 0)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
-
-    GemmP p;
+    if (epi == MOFO_EPI_BIAS_GELU && (!a->C2 || a->ldc2 % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: BIAS_GELU needs C2 (ldc2 multiple of 8)");
+    if (epi == MOFO_EPI_RESID_F32 && (!a->resid || a->ldr % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_F32 needs resid (ldr multiple of 4)");
+    if (epi == MOFO_EPI_DGELU_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: DGELU needs aux (ldaux multiple of 8)");
+    if (epi == MOFO_EPI_POS_F32 && (!a->pos || !a->row_idx || a->rows_in <= 0 || a->ldpos % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.C = a->C; p.C2 = a->C2;
     p.bias = a->bias; p.resid = a->resid; p.aux = (const bf16_t*)a->aux; p.pos = a->pos; p.row_idx = a->row_idx;
     p.M = a->M; p.N = a->N; p.K = a->K;
     p.lda = a->lda; p.ldb = a->ldb; p.ldc = a->ldc; p.ldc2 = a->ldc2; p.ldr = a->ldr; p.ldaux = a->ldaux; p.ldpos = a->ldpos;
     p.rows_in = a->rows_in; p.rows_out = a->rows_out; p.row_off = a->row_off;
-    int kps = ceil_div(ceil_div(a->K, splits), BK) * BK;
+    const int kps = ceil_div(ceil_div(a->K, splits), BK) * BK;
     splits = ceil_div(a->K, kps);
     p.k_per_split = kps;
     p.atomic = (splits > 1 || a->accumulate) ? 1 : 0;
-    hipStream_t s = (hipStream_t)stream;
+    blocks = ceil_div(a->M, BM) * ceil_div(a->N, BN) * splits;
+    return MOFO_OK;
+}
 
-#define GO(LA, LB, E) return launch<LA, LB, E>(p, splits, s)
+static int dispatch(int op, int epi, const GroupP& g, hipStream_t s) {
+#define GO(LA, LB, E) return launch<LA, LB, E>(g, s)
     if (op == MOFO_GEMM_NT) {
         switch (epi) {
             case MOFO_EPI_BF16: GO(OPL_ROW, OPL_ROW, MOFO_EPI_BF16);
@@ -268,4 +317,28 @@ extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
     }
 #undef GO
     MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: op %d with epilogue %d is not built", op, epi);
+}
+
+extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* stream) {
+    if (!a || count < 1 || count > MAXG) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d", MAXG);
+    GroupP g;
+    g.count = count;
+    g.start[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].op != a[0].op || a[i].epilogue != a[0].epilogue) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: problems must share op and epilogue");
+        int blocks = 0;
+        const int rc = fill_problem(&a[i], g.p[i], blocks);
+        if (rc) return rc;
+        g.start[i + 1] = g.start[i] + blocks;
+    }
+    for (int i = count; i < MAXG; ++i) {
+        g.p[i] = g.p[0];
+        g.start[i + 1] = g.start[count];
+    }
+    return dispatch(a[0].op, a[0].epilogue, g, (hipStream_t)stream);
+}
+
+extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
+    if (!a) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null args");
+    return mofo_gemm_grouped(a, 1, stream);
 }

@@ -178,8 +178,10 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
         MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_bwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
-    int blocks = ceil_div(M, 4);
+    // every block pays a fixed cost (weight load, 32 KiB LDS reduce, D atomics x2): give each wave >= 8 rows
+    int blocks = ceil_div(M, 32);
     if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(256);
 #define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }

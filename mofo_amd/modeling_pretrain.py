@@ -130,6 +130,7 @@ class _EncoderFn(torch.autograd.Function):
         mod, w = ctx.mod, ctx.w
         mod._ensure_grads()
         w.d_encout.copy_(g.reshape(w.Me, -1))
+        mod._rt.begin_backward()
         mod._rt.encoder_backward(w, w.d_encout)
         return None, None, None
 
@@ -149,6 +150,7 @@ class _DecoderFn(torch.autograd.Function):
         mod, w = ctx.mod, ctx.w
         mod._ensure_grads()
         w.dpred.copy_(g.reshape(w.Mm, -1))
+        mod._rt.begin_backward()
         dx = mod._rt.decoder_backward(w, w.dpred, w.x_full, ctx.n_ret)
         return dx.view(w.B, w.N, -1).clone(), None, None, None
 

@@ -42,8 +42,12 @@ def _p(t):
 
 
 def _run(name, key, work, *args):
-    """one C-ABI call on the current stream; optionally bracketed by HIP events (bench.py's per-kernel timing)"""
+    """one C-ABI call on the current stream; optionally recorded into a launch list (runtime replays it without the
+    Python-side checks) and optionally bracketed by HIP events (bench.py's per-kernel timing)"""
     fn = getattr(_lib.load(), name)
+    rec = _lib.RECORDER
+    if rec is not None:
+        rec.append((fn, args, name, key, work))
     prof = _lib.PROFILER
     if prof is None:
         _lib.check(fn(*args, _stream()), name)
@@ -53,9 +57,49 @@ def _run(name, key, work, *args):
         prof.end()
 
 
-def gemm(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
-         row_off=0, splits=1, accumulate=False):
+def host_op(f):
+    """a torch-side op (memset, hook) that must keep its place in the launch order of a recorded list"""
+    rec = _lib.RECORDER
+    if rec is not None:
+        rec.append((None, f, None, None, 0.0))
+    f()
+
+
+def replay(launches):
+    """re-issue a recorded launch list on the current stream (pointers and sizes were validated when it was recorded)"""
+    s = _stream()
+    prof = _lib.PROFILER
+    for fn, args, name, key, work in launches:
+        if fn is None:
+            args()
+        elif prof is None:
+            rc = fn(*args, s)
+            if rc:
+                _lib.check(rc, name)
+        else:
+            prof.begin(key, work)
+            rc = fn(*args, s)
+            prof.end()
+            if rc:
+                _lib.check(rc, name)
+
+
+def gemm(op, epi, A, B, C_, **kw):
     """C = epilogue(A (op) B).  A, B bf16 2-D; see include/mofo_hip.h for op / epilogue semantics."""
+    a, flops = _gemm_args(op, epi, A, B, C_, **kw)
+    _run("mofo_gemm", ("gemm", op, epi), flops, C.byref(a))
+    return C_
+
+
+def gemm_grouped(op, epi, problems):
+    """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 4)"""
+    built = [_gemm_args(op, epi, A, B, C_, **kw) for A, B, C_, kw in problems]
+    arr = (GemmArgs * len(built))(*[b[0] for b in built])
+    _run("mofo_gemm_grouped", ("gemm", op, epi), sum(b[1] for b in built), arr, len(built))
+
+
+def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
+               row_off=0, splits=1, accumulate=False):
     _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
     if op == GEMM_NT:
         M, K = A.shape
@@ -101,8 +145,7 @@ def gemm(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=Non
                  ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
                  rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0)
-    _run("mofo_gemm", ("gemm", op, epi), 2.0 * M * N * K, C.byref(a))
-    return C_
+    return a, 2.0 * M * N * K
 
 
 def colsum_bf16(X, out):

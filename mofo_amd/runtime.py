@@ -124,6 +124,7 @@ class FlatStore:
                 p.data = v
         self.attach_grads()
         self._shadow_version = -1
+        self.fresh = True
         self.numel = sum(p.numel() for _, p in named_params)
 
     def _slice(self, buf, name):
@@ -192,13 +193,17 @@ class FlatStore:
 
     def zero_grads(self):
         self.grads.zero_()
+        self.fresh = True    # the next backward may overwrite (plain stores) instead of accumulate
 
 
 # ======================================================================================================= runtime
 def _wsplits(P, Q, R):
+    """split the token reduction of a wgrad GEMM only when its 128x128 output tiles cannot fill the 256 CUs: every split
+    costs one more f32 atomic pass over the weight gradient (chip-wide atomic rate ~1.3 TB/s), an unsplit one plain stores"""
     tiles = ((P + 127) // 128) * ((Q + 127) // 128)
-    s = max(1, round(512 / tiles))
-    return int(max(1, min(s, R // 512)))
+    if tiles >= 96:
+        return 1
+    return int(max(1, min(-(-256 // tiles), 16, R // 1024)))
 
 
 class PretrainRuntime:
@@ -220,6 +225,7 @@ class PretrainRuntime:
             self.decW = [self._block_weights(f"{dec_prefix}blocks.{i}.") for i in range(dims.dec_depth)]
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
         self.segments = self.plan_segments()
+        self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
 
@@ -251,7 +257,7 @@ class PretrainRuntime:
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), dxbA=e(M, D), dxbB=e(M, D), dxln=e(M, D), dh1=e(M, hid), dqkv=e(M, 3 * D),
+        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), dxbA=e(M, D), dxbB=e(M, D), dxbC=e(M, D), dxln=e(M, D), dh1=e(M, hid), dqkv=e(M, 3 * D),
                   dao=e(M, D), delta=e(B * H * n, dt=F32))
 
     def ws(self, B: int, n_vis: Optional[int] = None, N: Optional[int] = None) -> NS:
@@ -326,30 +332,38 @@ class PretrainRuntime:
     def _wgrad(self, dY, X, G):
         R, P = dY.shape
         Q = X.shape[1]
-        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=True)
+        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=self._accumulate)
+
+    def _wgrad_group(self, problems):
+        """the weight gradients of one transformer block as ONE grouped launch: their 128x128 tiles together fill the
+        chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
+        R = problems[0][0].shape[0]
+        tiles = sum(((dY.shape[1] + 127) // 128) * ((X.shape[1] + 127) // 128) for dY, X, _ in problems)
+        splits = 1 if tiles >= 200 else int(max(1, min(-(-400 // tiles), 16, R // 1024)))
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
+                         [(dY, X, G, dict(splits=splits, accumulate=self._accumulate)) for dY, X, G in problems])
 
     def _block_bwd(self, W, L, S, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
-        """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in (may alias dx_out)."""
+        """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in.  dx_in may alias dx_out;
+        dxb_in must NOT alias dxb_out (the deferred weight-gradient launch at the end still reads dxb_out)."""
         scale = 64 ** -0.5
         D = x_in.shape[1]
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, S.dh1, aux=L.h1)
-        self._wgrad(dxb_out, L.g, W.g_fc2)
-        ops.colsum_bf16(dxb_out, W.g_fc2b)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dh1, W.fc1, S.dxln)
-        self._wgrad(S.dh1, L.xln2, W.g_fc1)
-        ops.colsum_bf16(S.dh1, W.g_fc1b)
         ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dx_out, S.dxB, S.dxbB, W.g_ln2w, W.g_ln2b)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dxbB, W.proj, S.dao)
-        self._wgrad(S.dxbB, L.ao, W.g_proj)
-        ops.colsum_bf16(S.dxbB, W.g_projb)
         ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, S.dqkv, S.delta)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dqkv, W.qkv, S.dxln)
-        self._wgrad(S.dqkv, L.xln1, W.g_qkv)
+        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
+        # parameter gradients of the whole block, off the activation-gradient chain
+        self._wgrad_group([(dxb_out, L.g, W.g_fc2), (S.dh1, L.xln2, W.g_fc1), (S.dxbB, L.ao, W.g_proj), (S.dqkv, L.xln1, W.g_qkv)])
+        ops.colsum_bf16(dxb_out, W.g_fc2b)
+        ops.colsum_bf16(S.dh1, W.g_fc1b)
+        ops.colsum_bf16(S.dxbB, W.g_projb)
         ops.colsum_bf16(S.dqkv[:, :D], W.g_qb)
         ops.colsum_bf16(S.dqkv[:, 2 * D:], W.g_vb)
-        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
 
     def plan_segments(self, blocks_per_bucket: int = 3) -> List[Tuple[int, int]]:
         """Contiguous ranges of the flat gradient buffer in the order backward completes them (the data-parallel
@@ -380,9 +394,30 @@ class PretrainRuntime:
         return [s.range_of(n) for n in segs]
 
     def _seg(self, idx: int):
+        ops.host_op(lambda: self._seg_now(idx))
+
+    def _seg_now(self, idx: int):
         if self.segment_hook is not None:
             lo, hi = self.segments[idx]
             self.segment_hook(idx, lo, hi)
+
+    def cached(self, w: NS, tag, fn):
+        """run ``fn`` (a fixed launch sequence over workspace ``w``) -- checked and recorded the first time, replayed as a
+        flat launch list afterwards (no tensor checks, no Python-side argument marshalling beyond ctypes)"""
+        cache = w.__dict__.setdefault("_lists", {})
+        lst = cache.get(tag)
+        if lst is None:
+            from . import _lib
+            rec = []
+            _lib.RECORDER = rec
+            try:
+                out = fn()
+            finally:
+                _lib.RECORDER = None
+            cache[tag] = (rec, out)
+            return out
+        ops.replay(lst[0])
+        return lst[1]
 
     # ------------------------------------------------------------------ encoder
     def encoder_forward(self, w: NS):
@@ -404,15 +439,17 @@ class PretrainRuntime:
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
         cnt = 0
+        cur, nxt = S.dxbA, S.dxbC
         for i in range(d.enc_depth - 1, -1, -1):
             x_in = w.enc[i - 1].x_out if i > 0 else w.enc_x0
-            self._block_bwd(self.encW[i], w.enc[i], S, x_in, S.dxA, S.dxbA, S.dxA, S.dxbA, w.B, w.n_vis, d.enc_heads)
+            self._block_bwd(self.encW[i], w.enc[i], S, x_in, S.dxA, cur, S.dxA, nxt, w.B, w.n_vis, d.enc_heads)
+            cur, nxt = nxt, cur
             cnt += 1
             if cnt == 3 and i > 0:  # gradient buckets of three encoder blocks (~85 MB fp32 at ViT-B)
                 self._seg(seg)
                 seg, cnt = seg + 1, 0
-        self._wgrad(S.dxbA, w.xp, s.g2d(p + "patch_embed.proj.weight"))
-        ops.colsum_bf16(S.dxbA, s.gview(p + "patch_embed.proj.bias"))
+        self._wgrad(cur, w.xp, s.g2d(p + "patch_embed.proj.weight"))
+        ops.colsum_bf16(cur, s.gview(p + "patch_embed.proj.bias"))
         self._seg(seg)
 
     # ------------------------------------------------------------------ bridge
@@ -449,32 +486,51 @@ class PretrainRuntime:
         self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"))
         ops.colsum_bf16(dpred_bf16, s.gview(p + "head.bias"))
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
-        S.dxA.zero_()
-        S.dxbA.zero_()   # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
+        # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
+        ops.host_op(lambda: (S.dxA.zero_(), S.dxbA.zero_()))
         ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, S.dxA, S.dxbA,
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        cur, nxt = S.dxbA, S.dxbC
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
-            self._block_bwd(self.decW[i], w.dec[i], S, x_in, S.dxA, S.dxbA, S.dxA, S.dxbA, w.B, w.N, d.dec_heads)
+            self._block_bwd(self.decW[i], w.dec[i], S, x_in, S.dxA, cur, S.dxA, nxt, w.B, w.N, d.dec_heads)
+            cur, nxt = nxt, cur
         return S.dxA
 
     # ------------------------------------------------------------------ whole model
-    def forward(self, w: NS):
+    def _forward(self, w: NS):
         enc_out = self.encoder_forward(w)
         x_full = self.bridge_forward(w, enc_out)
         return self.decoder_forward(w, x_full, w.n_msk)
 
-    def loss_forward(self, w: NS, normalize_target: bool = True, grad_scale: float = 1.0):
-        """engine_for_pretraining.py:43-67 fused: target build + MSE + d(loss)/d(pred) in one pass."""
+    def forward(self, w: NS):
+        return self.cached(w, "fwd", lambda: self._forward(w))
+
+    def _loss_forward(self, w, normalize_target, grad_scale):
         d = self.d
         ops.target_mse(w.clips, d.tubelet, d.patch_size, w.msk_idx, w.pred, normalize_target, grad_scale, w.row_loss, w.loss, w.dpred)
         return w.loss
 
-    def backward(self, w: NS):
+    def loss_forward(self, w: NS, normalize_target: bool = True, grad_scale: float = 1.0):
+        """engine_for_pretraining.py:43-67 fused: target build + MSE + d(loss)/d(pred) in one pass."""
+        return self.cached(w, ("loss", bool(normalize_target), float(grad_scale)),
+                           lambda: self._loss_forward(w, normalize_target, grad_scale))
+
+    def _backward(self, w: NS):
         dx_full = self.decoder_backward(w, w.dpred, w.x_full, w.n_msk)
         d_encout = self.bridge_backward(w, dx_full, w.enc_out)
         self._seg(0)
         self.encoder_backward(w, d_encout)
+
+    def begin_backward(self):
+        """decide overwrite vs accumulate for this backward's weight gradients (zero_grad since the last backward?)"""
+        st = self.store
+        self._accumulate = not st.fresh
+        st.fresh = False
+
+    def backward(self, w: NS):
+        self.begin_backward()
+        self.cached(w, ("bwd", self._accumulate), lambda: self._backward(w))
 
     # ------------------------------------------------------------------ optimizer side
     def grad_norm(self) -> torch.Tensor:

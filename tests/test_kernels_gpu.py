@@ -127,6 +127,28 @@ def test_gemm_tn_wgrad(dev, R, P, Q):
     assert _rel(C, 2 * ref) < 1e-5
 
 
+def test_gemm_grouped_wgrad(dev):
+    """four weight-gradient GEMMs of different shapes in one launch == four separate launches"""
+    from mofo_amd import ops
+    R = 320
+    shapes = [(768, 3072), (3072, 768), (768, 768), (2304, 768)]
+    probs, refs = [], []
+    for i, (P, Q) in enumerate(shapes):
+        dY, X = _rand((R, P), dev, 10 + i), _rand((R, Q), dev, 20 + i)
+        G = torch.zeros(P, Q, dtype=F32, device=dev)
+        probs.append((dY, X, G, dict(splits=1, accumulate=False)))
+        refs.append(dY.float().t() @ X.float())
+    ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs)
+    for (dY, X, G, _), ref in zip(probs, refs):
+        assert _rel(G, ref) < 1e-5
+    probs2 = [(dY, X, G, dict(splits=2, accumulate=True)) for dY, X, G, _ in probs[:3]]
+    ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs2)
+    for (dY, X, G, _), ref in zip(probs2, refs):
+        assert _rel(G, 2 * ref) < 1e-5
+    with pytest.raises(RuntimeError, match="count"):
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs + probs[:1])
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from mofo_amd import ops
     A = _rand((64, 96), dev, 1)
