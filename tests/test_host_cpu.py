@@ -1,0 +1,222 @@
+"""Host-side logic on CPU (no GPU, no /root/reference): drop-in API surface, mask generators and schedules against
+the reference fixtures, flat parameter store layout, gradient-bucket plan, and the data-parallel gradient exchange on
+two gloo ranks."""
+import os
+import socket
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+# ------------------------------------------------------------------------------------------------ masks / schedules
+def test_mask_generators_match_reference_fixtures():
+    from mofo_amd.masking_generator import TubeMaskingGenerator, TubeMaskingGenerator_BB
+    m = np.load(os.path.join(G, "masks.npz"))
+    for seed in (10, 0, 1, 2, 3):
+        np.random.seed(seed)
+        got = TubeMaskingGenerator((8, 14, 14), 0.9)()
+        assert got.dtype == np.float64 and np.array_equal(got.astype(np.uint8), m[f"tube_s{seed}"])
+    np.random.seed(7)
+    assert np.array_equal(TubeMaskingGenerator((16, 14, 14), 0.9)().astype(np.uint8), m["tube_l32_s7"])
+    for seed in (10, 0):
+        for i, b in enumerate(m["bb_boxes"]):
+            np.random.seed(seed)
+            got = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)(np.tile(b, (16, 1)))
+            assert np.array_equal(got.astype(np.uint8), m[f"bb_s{seed}"][i])
+            assert got.sum() == 1408
+    np.random.seed(5)
+    gen = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)
+    stream = np.stack([gen(np.tile(b, (16, 1))) for b in m["bb_boxes"]])
+    assert np.array_equal(stream.astype(np.uint8), m["bb_stream_s5"])
+    assert "total patches 1568, mask patches 1408" in repr(gen)
+
+
+def test_bb_mask_edge_cases():
+    from mofo_amd.masking_generator import TubeMaskingGenerator_BB
+    gen = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)
+    for box in ([0, 0, 0, 0], [223, 223, 224, 224], [0, 0, 224, 224], [-5, -5, -1, -1], [300, 300, 400, 400]):
+        np.random.seed(1)
+        msk = gen(np.tile(np.array(box), (16, 1)))
+        assert msk.shape == (1568,) and msk[:196].sum() == 176      # always exactly 176 masked per frame -> 160 visible
+        assert np.array_equal(msk.reshape(8, 196), np.tile(msk[:196], (8, 1)))
+
+
+def test_cosine_scheduler_and_sincos():
+    from mofo_amd import utils
+    from mofo_amd.runtime import sincos_table
+    g = np.load(os.path.join(G, "sched.npz"))
+    assert np.array_equal(utils.cosine_scheduler(1.5e-4, 1e-5, 10, 7, warmup_epochs=3), g["s1"])
+    assert np.array_equal(utils.cosine_scheduler(0.05, 0.05, 4, 5), g["s2"])
+    assert np.array_equal(utils.cosine_scheduler(1.2e-3, 1e-5, 6, 11, warmup_epochs=2, warmup_steps=9), g["s3"])
+    s = np.load(os.path.join(G, "sincos.npz"))
+    for n, d in ((1568, 768), (1568, 384), (3136, 1024)):
+        t = sincos_table(n, d)
+        assert np.array_equal(t[:4, :8].numpy(), s[f"t{n}x{d}_head"]) and np.array_equal(t[-4:, -8:].numpy(), s[f"t{n}x{d}_tail"])
+
+
+# ------------------------------------------------------------------------------------------------ API surface
+def test_state_dict_schema_and_factories():
+    from mofo_amd import modeling_pretrain as mp
+    from oracle import pretrain_oracle as O
+    m = mp.pretrain_videomae_base_patch16_224(decoder_depth=4)
+    sd = m.state_dict()
+    shapes = O.param_shapes(O.VIT_B)
+    assert list(sd) == list(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in sd)
+    assert sum(v.numel() for v in sd.values()) == 94_210_944
+    assert m.encoder.patch_embed.patch_size == (16, 16) and m.encoder.patch_embed.num_patches == 1568
+    assert m.no_weight_decay() == {'pos_embed', 'cls_token', 'mask_token'}
+    assert float(m.mask_token.abs().max()) <= 0.02 + 1e-9           # trunc_normal_(std=.02) clipped at +-std
+    for blk in m.encoder.blocks[:1]:
+        assert torch.all(blk.attn.q_bias == 0) and torch.all(blk.norm1.weight == 1) and torch.all(blk.mlp.fc1.bias == 0)
+    mm = mp.create_model('pretrain_videomae_base_patch16_224', pretrained=False, drop_path_rate=0.0, drop_block_rate=None, decoder_depth=4)
+    assert len(mm.decoder.blocks) == 4
+    small = mp.pretrain_mae_small_patch16_224(decoder_depth=2)
+    assert small.encoder.embed_dim == 384 and small.decoder.embed_dim == 192
+    # a reference checkpoint's 'model' dict loads by name
+    ref_like = {k: torch.randn(s) for k, s in shapes.items()}
+    assert not m.load_state_dict(ref_like, strict=True).missing_keys
+
+
+def test_unsupported_options_raise_loudly():
+    from mofo_amd import modeling_pretrain as mp
+    for kw in (dict(drop_path_rate=0.1), dict(drop_rate=0.1), dict(attn_drop_rate=0.1), dict(init_values=0.1),
+               dict(use_learnable_pos_emb=True), dict(qk_scale=0.5)):
+        with pytest.raises(NotImplementedError):
+            mp.pretrain_videomae_base_patch16_224(decoder_depth=1, **kw)
+    with pytest.raises(NotImplementedError):
+        mp.PretrainVisionTransformer(qkv_bias=False)
+    with pytest.raises(NotImplementedError, match="head_dim"):
+        mp.PretrainVisionTransformerEncoder(embed_dim=768, num_heads=8, qkv_bias=True)
+    m = mp.pretrain_videomae_base_patch16_224(decoder_depth=1)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 16, 224, 224), torch.zeros(1, 1568, dtype=torch.bool))
+
+
+def test_optimizer_groups_and_errors():
+    from mofo_amd import modeling_pretrain as mp
+    from mofo_amd import optim_factory
+    m = mp.pretrain_videomae_base_patch16_224(decoder_depth=4)
+    groups, names = optim_factory.get_parameter_groups(m, 0.05, m.no_weight_decay())
+    sizes = {k: len(v) for k, v in names.items()}
+    assert sizes == {"no_decay": 151, "decay": 67}
+    assert list(names)[0] == "no_decay" and "mask_token" in names["no_decay"] and "encoder.patch_embed.proj.weight" in names["decay"]
+    assert all("attn.q_bias" not in n for n in names["decay"])
+
+    class A:
+        opt, lr, weight_decay, opt_eps, opt_betas = "sgd", 1e-3, 0.05, 1e-8, (0.9, 0.95)
+    with pytest.raises(NotImplementedError):
+        optim_factory.create_optimizer(A, m)
+
+
+# ------------------------------------------------------------------------------------------------ flat store
+def _tiny_model():
+    from mofo_amd import modeling_pretrain as mp
+    return mp.PretrainVisionTransformer(img_size=32, encoder_embed_dim=128, encoder_depth=5, encoder_num_heads=2, decoder_embed_dim=64,
+                                        decoder_depth=1, decoder_num_heads=1, decoder_num_classes=1536, qkv_bias=True,
+                                        norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+
+
+def _cpu_runtime(model):
+    from mofo_amd.runtime import FlatStore, PretrainRuntime
+    named = dict(model.named_parameters())
+    store = FlatStore([(n, named[n]) for n in model._flat_order()], torch.device("cpu"), skip_decay=model.no_weight_decay())
+    return PretrainRuntime(model._make_runtime.__func__(model, store).d, store), store
+
+
+def test_flat_store_layout_and_views():
+    model = _tiny_model()
+    before = {k: v.clone() for k, v in model.state_dict().items()}
+    rt, st = _cpu_runtime(model)
+    assert st.total % 1024 == 0 and st.owns(full=True) and st.grads_attached()
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, before[k])                               # values survived the move into the flat buffer
+    # parameters ARE views: writing the flat buffer changes the module, load_state_dict writes the flat buffer
+    st.params.zero_()
+    assert all(float(p.abs().sum()) == 0 for p in model.parameters())
+    model.load_state_dict(before)
+    assert torch.equal(st.view("decoder.head.weight"), before["decoder.head.weight"])
+    # fused qkv bias = (q_bias | zeros | v_bias), zero third is not a parameter
+    fb = st.fused_bias("encoder.blocks.0.attn.q_bias")
+    assert fb.numel() == 384 and torch.equal(fb[:128], before["encoder.blocks.0.attn.q_bias"]) and torch.all(fb[128:256] == 0)
+    # decay flags: chunk_group 0 = decayed (>=2-D weights), 1 = everything else incl. padding
+    cg = st.chunk_group.numpy()
+    o = st.offset["encoder.blocks.0.mlp.fc1.weight"] // 1024
+    assert cg[o] == 0 and cg[st.offset["encoder.blocks.0.mlp.fc1.bias"] // 1024] == 1 and cg[st.offset["mask_token"] // 1024] == 1
+    decayed = sum(int(np.prod(s)) for n, s in st.shape.items() if len(s) > 1 and n != "mask_token")
+    assert (cg == 0).sum() * 1024 >= decayed
+    # version tracking: in-place write through a Parameter is seen
+    v0 = st._version()
+    with torch.no_grad():
+        model.mask_token.add_(1.0)
+    assert st._version() != v0
+    # zero_grad(set_to_none) detaches; re-attach restores the views
+    for p in model.parameters():
+        p.grad = None
+    assert not st.grads_attached()
+    st.attach_grads()
+    assert st.grads_attached()
+
+
+def test_gradient_segments_tile_the_buffer():
+    model = _tiny_model()
+    rt, st = _cpu_runtime(model)
+    segs = rt.segments
+    assert len(segs) == 3                                             # decoder group + 2 encoder groups (5 blocks -> 3 + 2)
+    ranges = sorted(segs)
+    assert ranges[0][0] == 0 and ranges[-1][1] == st.total
+    for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
+        assert a1 == b0                                                # contiguous, no gap, no overlap
+    # completion order = decoder first, then encoder from the top
+    assert segs[0][1] == st.total and segs[-1][0] == 0
+
+
+# ------------------------------------------------------------------------------------------------ DP on two gloo ranks
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from mofo_amd.dist import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                                      # different init per rank on purpose
+    model = _tiny_model()
+    rt, st = _cpu_runtime(model)
+    model.runtime = lambda: rt
+    dist.broadcast(st.params, src=0)                                   # what DataParallel.__init__ does
+    sync = GradSync(model).install()
+    assert sync.enabled
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(st.total, generator=g)
+    st.grads.copy_(local / world)                                      # loss kernel pre-scales d(loss) by 1/world
+    for idx in range(len(rt.segments)):                                # backward completes segment after segment
+        rt._seg_now(idx)
+    launched = list(sync.launched)
+    sync.finish()
+    torch.save({"params": st.params.clone(), "grads": st.grads.clone(), "local": local, "launched": launched}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_mean_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    out = str(tmp_path / "dp")
+    mp.spawn(_dp_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(out + f".{i}") for i in range(world)]
+    assert torch.equal(r[0]["params"], r[1]["params"])                 # replicas start identical (rank 0's weights)
+    mean = (r[0]["local"] + r[1]["local"]) / world
+    for i in range(world):
+        assert torch.allclose(r[i]["grads"], mean, rtol=1e-6, atol=1e-7)   # SUM of pre-scaled grads == DDP mean
+    assert torch.equal(r[0]["grads"], r[1]["grads"])                   # bit-identical on every rank
+    assert [x[0] for x in r[0]["launched"]] == [0, 1, 2]               # one all-reduce per segment, in completion order
+    cover = sorted((lo, hi) for _, lo, hi in r[0]["launched"])
+    assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
