@@ -51,6 +51,8 @@ typedef struct mofo_gemm_args {
     int rows_in, rows_out, row_off; /* POS_F32: out row = (m / rows_in) * rows_out + row_off + m % rows_in */
     int splits;                   /* split the reduction over gridDim.z (F32 epilogue only) */
     int accumulate;               /* F32 epilogue: add into C instead of overwrite */
+    float* colsum;                /* TN + F32 only (wgrad): colsum[m] += sum_k A[k,m] = the bias gradient, fused; or NULL */
+    int colsum_skip_lo, colsum_skip_hi; /* rows m in [lo,hi) of colsum are left untouched (k third of the fused qkv bias) */
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
 /* up to 4 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of a transformer block) */

@@ -23,7 +23,7 @@ class GemmArgs(C.Structure):
                 ("A", _vp), ("lda", _i), ("B", _vp), ("ldb", _i), ("C", _vp), ("ldc", _i), ("C2", _vp), ("ldc2", _i),
                 ("bias", _vp), ("resid", _vp), ("ldr", _i), ("aux", _vp), ("ldaux", _i),
                 ("pos", _vp), ("ldpos", _i), ("row_idx", _vp), ("rows_in", _i), ("rows_out", _i), ("row_off", _i),
-                ("splits", _i), ("accumulate", _i)]
+                ("splits", _i), ("accumulate", _i), ("colsum", _vp), ("colsum_skip_lo", _i), ("colsum_skip_hi", _i)]
 
 
 _SIGS = {

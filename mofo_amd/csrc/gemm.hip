@@ -42,6 +42,8 @@ struct GemmP {
     int rows_in, rows_out, row_off;
     int k_per_split;
     int atomic;
+    float* colsum;            // TN only: colsum[m] += sum_k A[k,m]  (bias gradient riding on the wgrad GEMM), or null
+    int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
 };
 
 constexpr int MAXG = 4;
@@ -137,6 +139,16 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // bias gradient on the wgrad GEMM: one extra MFMA per m-subtile against an all-ones fragment gives sum_k A[k,m]
+    // (replaces a separate column-sum kernel that re-read every dY).  Only the first n-tile's wn==0 waves do it.
+    constexpr bool CAN_COLSUM = (LA == OPL_COL && LB == OPL_COL && EPI == MOFO_EPI_F32);
+    const bool do_colsum = CAN_COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
+    f32x4 accb[4];
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     auto stage = [&](int t, int buf) {
         unsigned char* ta = smem + buf * 2 * TILE_BYTES;
@@ -164,12 +176,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            if constexpr (CAN_COLSUM) {
+                if (do_colsum) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                }
+            }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         cur ^= 1;
     }
 
+    if constexpr (CAN_COLSUM) {
+        if (do_colsum && lane < 16) {   // D[n][m]: every row n holds the same sum; lanes 0..15 hold m = 16 i + lane in element 0
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + wm * 64 + 16 * i + lane;
+                if (m < p.M && !(m >= p.colsum_skip_lo && m < p.colsum_skip_hi)) atomicAdd(p.colsum + m, accb[i][0]);
+            }
+        }
+    }
     // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
     float* ep = (float*)smem + wave * 4096;
 #pragma unroll
@@ -289,6 +316,10 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int& blocks) {
     splits = ceil_div(a->K, kps);
     p.k_per_split = kps;
     p.atomic = (splits > 1 || a->accumulate) ? 1 : 0;
+    p.colsum = a->colsum;
+    p.colsum_skip_lo = a->colsum_skip_lo;
+    p.colsum_skip_hi = a->colsum_skip_hi;
+    if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
     blocks = ceil_div(a->M, BM) * ceil_div(a->N, BN) * splits;
     return MOFO_OK;
 }

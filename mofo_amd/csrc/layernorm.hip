@@ -178,8 +178,9 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
         MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_bwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
-    // every block pays a fixed cost (weight load, 32 KiB LDS reduce, D atomics x2): give each wave >= 8 rows
-    int blocks = ceil_div(M, 32);
+    // every block pays a fixed cost (weight load, LDS reduce, 2 D atomics); 2 rows per wave keeps >= 2 blocks per CU busy
+    // at the encoder's M = 5120 while bounding the atomic traffic (1024 blocks x 2 D floats)
+    int blocks = ceil_div(M, 8);
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(256);

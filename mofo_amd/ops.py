@@ -99,7 +99,7 @@ def gemm_grouped(op, epi, problems):
 
 
 def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
-               row_off=0, splits=1, accumulate=False):
+               row_off=0, splits=1, accumulate=False, colsum=None, colsum_skip=(0, 0)):
     _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
     if op == GEMM_NT:
         M, K = A.shape
@@ -140,11 +140,16 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         _chk(aux, BF16, "aux", 2)
         if tuple(aux.shape) != (M, N):
             raise ValueError("aux shape")
+    if colsum is not None:
+        _chk(colsum, F32, "colsum", 1)
+        if colsum.numel() != M or op != GEMM_TN or epi != EPI_F32:
+            raise ValueError("colsum: f32 [M], TN + F32 epilogue only")
     a = GemmArgs(op=op, epilogue=epi, M=M, N=N, K=K, A=_p(A), lda=_ld(A), B=_p(B), ldb=_ld(B), C=_p(C_), ldc=_ld(C_),
                  C2=_p(C2), ldc2=_ld(C2) if C2 is not None else 0, bias=_p(bias), resid=_p(resid),
                  ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
-                 rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0)
+                 rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0, colsum=_p(colsum),
+                 colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1])
     return a, 2.0 * M * N * K
 
 

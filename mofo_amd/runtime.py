@@ -234,7 +234,7 @@ class PretrainRuntime:
         s = self.store
         return NS(prefix=p,
                   ln1w=s.view(p + "norm1.weight"), ln1b=s.view(p + "norm1.bias"), g_ln1w=s.gview(p + "norm1.weight"), g_ln1b=s.gview(p + "norm1.bias"),
-                  qkvb=s.fused_bias(p + "attn.q_bias"), g_qb=s.gview(p + "attn.q_bias"), g_vb=s.gview(p + "attn.v_bias"),
+                  qkvb=s.fused_bias(p + "attn.q_bias"), g_qkvb=s.fused_bias(p + "attn.q_bias", s.grads),
                   qkv=s.bview(p + "attn.qkv.weight"), g_qkv=s.g2d(p + "attn.qkv.weight"),
                   proj=s.bview(p + "attn.proj.weight"), g_proj=s.g2d(p + "attn.proj.weight"),
                   projb=s.view(p + "attn.proj.bias"), g_projb=s.gview(p + "attn.proj.bias"),
@@ -329,19 +329,21 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
         return L.x_out
 
-    def _wgrad(self, dY, X, G):
+    def _wgrad(self, dY, X, G, bias_grad=None):
+        """dW (+)= dY^T X, and the bias gradient db += colsum(dY) fused into the same launch"""
         R, P = dY.shape
         Q = X.shape[1]
-        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=self._accumulate)
+        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=self._accumulate, colsum=bias_grad)
 
     def _wgrad_group(self, problems):
         """the weight gradients of one transformer block as ONE grouped launch: their 128x128 tiles together fill the
         chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
         R = problems[0][0].shape[0]
-        tiles = sum(((dY.shape[1] + 127) // 128) * ((X.shape[1] + 127) // 128) for dY, X, _ in problems)
+        tiles = sum(((pr[0].shape[1] + 127) // 128) * ((pr[1].shape[1] + 127) // 128) for pr in problems)
         splits = 1 if tiles >= 200 else int(max(1, min(-(-400 // tiles), 16, R // 1024)))
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
-                         [(dY, X, G, dict(splits=splits, accumulate=self._accumulate)) for dY, X, G in problems])
+                         [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
+                          for dY, X, G, bg, skip in problems])
 
     def _block_bwd(self, W, L, S, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
         """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in.  dx_in may alias dx_out;
@@ -358,12 +360,9 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dqkv, W.qkv, S.dxln)
         ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block, off the activation-gradient chain
-        self._wgrad_group([(dxb_out, L.g, W.g_fc2), (S.dh1, L.xln2, W.g_fc1), (S.dxbB, L.ao, W.g_proj), (S.dqkv, L.xln1, W.g_qkv)])
-        ops.colsum_bf16(dxb_out, W.g_fc2b)
-        ops.colsum_bf16(S.dh1, W.g_fc1b)
-        ops.colsum_bf16(S.dxbB, W.g_projb)
-        ops.colsum_bf16(S.dqkv[:, :D], W.g_qb)
-        ops.colsum_bf16(S.dqkv[:, 2 * D:], W.g_vb)
+        # (weights + biases; the bias gradients are column sums of the same dY operands, fused into the GEMMs)
+        self._wgrad_group([(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (S.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
+                           (S.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (S.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))])
 
     def plan_segments(self, blocks_per_bucket: int = 3) -> List[Tuple[int, int]]:
         """Contiguous ranges of the flat gradient buffer in the order backward completes them (the data-parallel
@@ -448,8 +447,7 @@ class PretrainRuntime:
             if cnt == 3 and i > 0:  # gradient buckets of three encoder blocks (~85 MB fp32 at ViT-B)
                 self._seg(seg)
                 seg, cnt = seg + 1, 0
-        self._wgrad(cur, w.xp, s.g2d(p + "patch_embed.proj.weight"))
-        ops.colsum_bf16(cur, s.gview(p + "patch_embed.proj.bias"))
+        self._wgrad(cur, w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
         self._seg(seg)
 
     # ------------------------------------------------------------------ bridge
@@ -483,8 +481,7 @@ class PretrainRuntime:
     def decoder_backward(self, w: NS, dpred_bf16: torch.Tensor, x_full: torch.Tensor, n_ret: int):
         d, s, p, S = self.d, self.store, self.dec_prefix, w.dec_s
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, dpred_bf16, s.bview(p + "head.weight"), w.d_decln)
-        self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"))
-        ops.colsum_bf16(dpred_bf16, s.gview(p + "head.bias"))
+        self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"))
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
         ops.host_op(lambda: (S.dxA.zero_(), S.dxbA.zero_()))

@@ -127,6 +127,22 @@ def test_gemm_tn_wgrad(dev, R, P, Q):
     assert _rel(C, 2 * ref) < 1e-5
 
 
+def test_gemm_wgrad_fused_bias_grad(dev):
+    """bias gradient (column sums of dY) riding on the wgrad GEMM via a ones-vector MFMA, with a skipped row range"""
+    from mofo_amd import ops
+    for R, P, Q, splits in [(320, 2304, 768, 1), (1568, 384, 1536, 3), (100, 192, 64, 1)]:
+        dY, X = _rand((R, P), dev, 1), _rand((R, Q), dev, 2)
+        G = torch.zeros(P, Q, dtype=F32, device=dev)
+        bg = torch.full((P,), 0.5, dtype=F32, device=dev)
+        lo, hi = P // 3, 2 * P // 3
+        ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=splits, accumulate=splits > 1, colsum=bg, colsum_skip=(lo, hi))
+        assert _rel(G, dY.float().t() @ X.float()) < 1e-5
+        ref = dY.float().sum(0) + 0.5
+        ref[lo:hi] = 0.5
+        assert _rel(bg, ref) < 1e-5
+        assert torch.all(bg[lo:hi] == 0.5)
+
+
 def test_gemm_grouped_wgrad(dev):
     """four weight-gradient GEMMs of different shapes in one launch == four separate launches"""
     from mofo_amd import ops
