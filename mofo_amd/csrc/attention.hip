@@ -69,18 +69,35 @@ __device__ __forceinline__ void store_T(bf16_t* dst_row, const f32x16& a0, const
     }
 }
 
+// XCD-aware block decode.  Blocks are dealt round-robin over the 8 XCDs (private L2s), so the NX blocks that share one
+// (clip, head)'s K/V (or Q/dO) must have block ids that are EQUAL mod 8, otherwise every XCD re-fetches the same K/V
+// (measured: FETCH_SIZE 5x the algorithmic bytes, TA/TC 93 % busy).  1-D grid of 8 * ceil(G/8) * NX blocks:
+// id -> xcd = id & 7, slot = id >> 3 -> group = (slot / NX) * 8 + xcd, x = slot % NX.  Speed only, never correctness.
+__device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int& b, int& h) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int gl = slot / nx;
+    xb = slot - gl * nx;
+    const int g = gl * 8 + xcd;
+    if (g >= G) return false;
+    b = g / H;
+    h = g - b * H;
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------ forward
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 template <int NW, int MODE>
-__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int N, int H, float c,
+__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
                                                           bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
+    int xb, b, h;
+    if (!decode_block(nx, G, H, xb, b, h)) return;
     const int D = H * HD;
-    const int q0 = (blockIdx.x * NW + wave) * 32;
+    const int q0 = (xb * NW + wave) * 32;
     const bf16_t* base = qkv + (size_t)b * N * ldqkv;
     const bf16_t* qp = base + h * HD;
     const bf16_t* kp = base + D + h * HD;
@@ -146,30 +163,35 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         const bool tail = (kt * 32 + 32 > N);
         float p[16];
         if constexpr (MODE == 0) {
+            // running max m is kept in RAW score units; p = exp2(c * s - c * m) is one FMA + one v_exp per element
             float mx = NEG_BIG;
+            if (tail) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s[r] * c;
-                if (tail && (kt * 32 + acc_row(r, hh) >= N)) x = NEG_BIG;
-                p[r] = x;
-                mx = fmaxf(mx, x);
+                for (int r = 0; r < 16; ++r)
+                    if (kt * 32 + acc_row(r, hh) >= N) s[r] = NEG_BIG;
             }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m, mx);
-            const float alpha = fast_exp2(m - mn);
+            const float nmc = -mn * c;
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                p[r] = fast_exp2(p[r] - mn);
+                p[r] = fast_exp2(fmaf(s[r], c, nmc));
                 ls += p[r];
             }
-            l = l * alpha + ls;
-            m = mn;
+            if (__any(mn > m)) {   // wave-uniform: after the first tiles the running max rarely moves
+                const float alpha = fast_exp2((m - mn) * c);
+                l *= alpha;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                o0[r] *= alpha;
-                o1[r] *= alpha;
+                for (int r = 0; r < 16; ++r) {
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
             }
+            l += ls;
+            m = mn;
             const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 0, lane), pf0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 0, lane), pf1, o0, 0, 0, 0);
@@ -201,7 +223,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         const float lt = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / lt;
         store_T(out + ((size_t)b * N + qi) * ldo + h * HD, o0, o1, inv, hh);
-        if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m + fast_log2(lt);
+        if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m * c + fast_log2(lt);
     } else {
         store_T(dqkv + ((size_t)b * N + qi) * lddqkv + h * HD, o0, o1, scale, hh);
     }
@@ -209,7 +231,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------ dK, dV
 template <int NW>
-__global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int N, int H, float c,
+__global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int lddqkv) {
@@ -217,9 +239,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     constexpr int BUF = 2 * TILE + 256;
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y;
+    int xb, b, h;
+    if (!decode_block(nx, G, H, xb, b, h)) return;
     const int D = H * HD;
-    const int k0 = (blockIdx.x * NW + wave) * 32;
+    const int k0 = (xb * NW + wave) * 32;
     const bf16_t* base = qkv + (size_t)b * N * ldqkv;
     const bf16_t* qp = base + h * HD;
     const bf16_t* kp = base + D + h * HD;
@@ -321,14 +344,15 @@ int pick_nw(int N) {
 }  // namespace
 
 #define LAUNCH_Q(NW, MODE)                                                                                              \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE>), dim3(ceil_div(N, 32 * NW), H, B), dim3(NW * 64), 0, s, (const bf16_t*)qkv, \
-                       ldqkv, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,     \
+                       (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
+                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
 
 static int check_common(const char* who, const void* qkv, int ldqkv, int B, int N, int H) {
     if (!qkv) MOFO_FAIL(MOFO_EINVAL, "%s: null qkv", who);
     if (B <= 0 || N <= 0 || H <= 0) MOFO_FAIL(MOFO_EINVAL, "%s: bad dims B=%d N=%d H=%d", who, B, N, H);
     if (ldqkv < 3 * H * 64 || ldqkv % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: ldqkv=%d must be >= 3*H*64 and a multiple of 8", who, ldqkv);
-    if (H > 65535 || B > 65535) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: grid too large", who);
+    if ((long long)B * H * ((N + 127) / 128) > (1LL << 28)) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: grid too large", who);
     return MOFO_OK;
 }
 
@@ -368,8 +392,9 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
     }
     MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
 #define LAUNCH_KV(NW)                                                                                                  \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW>), dim3(ceil_div(N, 32 * NW), H, B), dim3(NW * 64), 0, s, (const bf16_t*)qkv, \
-                       ldqkv, N, H, c, scale, (const bf16_t*)dout, lddo, (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
+    hipLaunchKernelGGL((attn_dkv_kernel<NW>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,       \
+                       (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
+                       (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
     switch (nw) {
         case 7: LAUNCH_KV(7); break;
         case 5: LAUNCH_KV(5); break;

@@ -63,6 +63,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
 }
 
+// Two rows per wave per iteration: both rows' loads are issued before either row's shuffle reductions, so the HBM
+// latency of one row hides behind the arithmetic of the other (the one-row form ran at 2-2.8 TB/s in the step).
 template <int NIT>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ x,
                                                       int ldx, const float* __restrict__ w, const float* __restrict__ mean,
@@ -80,46 +82,66 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
         aw[it] = f32x4{0.f, 0.f, 0.f, 0.f};
         ab[it] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    for (int r = blockIdx.x * 4 + wave; r < M; r += gridDim.x * 4) {
-        const size_t xr = map_row(r, rows_in, rows_out, row_off);
-        const float mu = mean[r], rs = rstd[r];
-        f32x4 xh[NIT], g[NIT];
-        float c1 = 0.f, c2 = 0.f;
+    const int stride = gridDim.x * 4;
+    for (int r0 = blockIdx.x * 4 + wave; r0 < M; r0 += 2 * stride) {
+        int rr[2] = {r0, r0 + stride};
+        const bool has2 = rr[1] < M;
+        if (!has2) rr[1] = r0;
+        size_t xr[2];
+        float mu[2], rs[2];
+        f32x4 xv[2][NIT], rv[2][NIT];
+        u32x2 dv[2][NIT];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c = (it * 64 + lane) * 4;
-            if (c < D) {
-                const f32x4 xv = *(const f32x4*)(x + xr * ldx + c);
-                const u32x2 dv = *(const u32x2*)(dy + (size_t)r * lddy + c);
-                const float d[4] = {bf16lo_to_f32(dv[0]), bf16hi_to_f32(dv[0]), bf16lo_to_f32(dv[1]), bf16hi_to_f32(dv[1])};
+        for (int k = 0; k < 2; ++k) {
+            xr[k] = map_row(rr[k], rows_in, rows_out, row_off);
+            mu[k] = mean[rr[k]];
+            rs[k] = rstd[rr[k]];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 4;
+                if (c < D) {
+                    xv[k][it] = *(const f32x4*)(x + xr[k] * ldx + c);
+                    dv[k][it] = *(const u32x2*)(dy + (size_t)rr[k] * lddy + c);
+                    rv[k][it] = dres ? *(const f32x4*)(dres + xr[k] * lddres + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                } else {
+                    xv[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    dv[k][it] = u32x2{0u, 0u};
+                    rv[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !has2) break;
+            f32x4 xh[NIT], g[NIT];
+            float c1 = 0.f, c2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const float d[4] = {bf16lo_to_f32(dv[k][it][0]), bf16hi_to_f32(dv[k][it][0]), bf16lo_to_f32(dv[k][it][1]), bf16hi_to_f32(dv[k][it][1])};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[it][e] = (xv[e] - mu) * rs;
+                    xh[it][e] = (xv[k][it][e] - mu[k]) * rs[k];
                     g[it][e] = d[e] * wv[it][e];
                     c1 += g[it][e];
                     c2 += g[it][e] * xh[it][e];
                     aw[it][e] += d[e] * xh[it][e];
                     ab[it][e] += d[e];
                 }
-            } else {
-                xh[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                g[it] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-        }
-        c1 = wave_sum(c1) / D;
-        c2 = wave_sum(c2) / D;
+            c1 = wave_sum(c1) / D;
+            c2 = wave_sum(c2) / D;
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int c = (it * 64 + lane) * 4;
-            if (c < D) {
-                f32x4 o;
+            for (int it = 0; it < NIT; ++it) {
+                const int c = (it * 64 + lane) * 4;
+                if (c < D) {
+                    f32x4 o;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = rs * (g[it][e] - c1 - xh[it][e] * c2);
-                if (dres) o += *(const f32x4*)(dres + xr * lddres + c);
-                *(f32x4*)(dx + xr * lddx + c) = o;
-                if (dxb) {
-                    u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-                    *(u32x2*)(dxb + xr * lddxb + c) = pk;
+                    for (int e = 0; e < 4; ++e) o[e] = rs[k] * (g[it][e] - c1 - xh[it][e] * c2) + rv[k][it][e];
+                    *(f32x4*)(dx + xr[k] * lddx + c) = o;
+                    if (dxb) {
+                        u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+                        *(u32x2*)(dxb + xr[k] * lddxb + c) = pk;
+                    }
                 }
             }
         }
