@@ -130,8 +130,9 @@ def main():
     full = None
     n_instr = 0
     for it in range(args.warmup):
-        if not args.no_kernel_events and (it >= 1 or args.warmup == 1) and full is None:
-            full = _lib.EventProfiler()          # the first warm-up step is cold (module load, first touch): not profiled
+        if not args.no_kernel_events and (it >= min(2, args.warmup - 1)) and full is None:
+            full = _lib.EventProfiler()          # step 0 is cold (module load, first touch, list recording) and step 1 is
+                                                 # the first replay: neither is profiled when there are >= 3 warm-up steps
             _lib.PROFILER = full
         n_instr += full is not None
         step(it)
@@ -198,7 +199,7 @@ def main():
                 rate = v["work"] / (v["ms"] * 1e-3)
                 mf = k[0] in ("gemm", "attn_fwd", "attn_bwd")
                 print(f"{names.get(k, '_'.join(str(x) for x in k)):28s} {v['launches'] // max(1, n_instr):8d} {v['ms'] / max(1, n_instr):9.3f} "
-                      f"{v['ms'] / wtot:6.1%} {rate / (1e12 if mf else 1e9):9.1f} {'TF/s' if mf else 'GB/s'}", file=sys.stderr)
+                      f"{v['ms'] / wtot:6.1%} {rate / (1e12 if mf else 1e9):9.1f} {'TF/s' if mf else 'GB/s'}  (max {v['max_ms']:.3f} ms)", file=sys.stderr)
             print(f"sum of kernel time {wtot / max(1, n_instr):.3f} ms/step (warm-up) vs timed wall {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)
 
     if rank == 0:

@@ -77,30 +77,32 @@ class EventProfiler:
         self._cur = None
         self.only = only    # bracket just this kernel class (each event costs ~5 us of host time)
 
-    def begin(self, key, work=0.0):
+    def begin(self, key, work=0.0, stream=None):
         if self.only is not None and key != self.only:
             self._cur = None
             return
         e0 = torch.cuda.Event(enable_timing=True)
-        e0.record()
+        e0.record(stream) if stream is not None else e0.record()
         self._cur = (key, work, e0)
 
-    def end(self):
+    def end(self, stream=None):
         if self._cur is None:
             return
         key, work, e0 = self._cur
         e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
+        e1.record(stream) if stream is not None else e1.record()
         self.records.append((key, work, e0, e1))
 
     def summary(self):
         torch.cuda.synchronize()
         out = {}
         for key, work, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "work": 0.0, "max_ms": 0.0})
+            t = e0.elapsed_time(e1)
             d["launches"] += 1
-            d["ms"] += e0.elapsed_time(e1)
+            d["ms"] += t
             d["work"] += work
+            d["max_ms"] = max(d["max_ms"], t)
         return out
 
 

@@ -24,6 +24,7 @@
 // without split-K (every split costs another f32 atomic pass over the gradient).
 #include "common.h"
 #include "../../include/mofo_hip.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -106,9 +107,13 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
     }
 }
 
-template <int LA, int LB, int EPI>
-__global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILE_BYTES];  // [buf][A|B]
+// VAR 0: two LDS stages (64 KiB, 2 blocks/CU).  VAR 1: ONE LDS stage (32 KiB, 3 blocks/CU by VGPRs) with register
+// double-buffering: all fragments of tile t are read into VGPRs, barrier, tile t+1's LDS-DMA is issued into the same
+// LDS buffer and flies while the 32 MFMAs of tile t run from registers.  More resident blocks per CU let one block's
+// (HBM-bound) epilogue overlap another's main loop; the model's short reductions (K = 384..3072) need that.
+template <int LA, int LB, int EPI, int VAR>
+__global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(VAR == 0 ? 4 : 2) * TILE_BYTES];  // [buf][A|B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int gi = 0;
@@ -159,33 +164,67 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
     if (nk > 0) stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const unsigned char* ta = smem + cur * 2 * TILE_BYTES;
-        const unsigned char* tb = ta + TILE_BYTES;
+    if constexpr (VAR == 0) {
+        int cur = 0;
+        for (int t = 0; t < nk; ++t) {
+            if (t + 1 < nk) stage(t + 1, cur ^ 1);
+            const unsigned char* ta = smem + cur * 2 * TILE_BYTES;
+            const unsigned char* tb = ta + TILE_BYTES;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[4], bfr[4];
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[4], bfr[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = read_frag<LA>(ta, wm * 64 + 16 * i, ks, lane);
+                for (int i = 0; i < 4; ++i) af[i] = read_frag<LA>(ta, wm * 64 + 16 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) bfr[i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
+                for (int i = 0; i < 4; ++i) bfr[i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-            if constexpr (CAN_COLSUM) {
-                if (do_colsum) {
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+                if constexpr (CAN_COLSUM) {
+                    if (do_colsum) {
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                    }
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            cur ^= 1;
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
+    } else {
+        const unsigned char* ta = smem;
+        const unsigned char* tb = smem + TILE_BYTES;
+        for (int t = 0; t < nk; ++t) {
+            bf16x8 af[2][4], bfr[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<LA>(ta, wm * 64 + 16 * i, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[ks][i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave holds tile t in registers: the LDS buffer is free
+            if (t + 1 < nk) stage(t + 1, 0);       // tile t+1 flies while tile t is multiplied from registers
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+                if constexpr (CAN_COLSUM) {
+                    if (do_colsum) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
+                    }
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // tile t+1 landed and is visible to every wave
+        }
     }
 
     if constexpr (CAN_COLSUM) {
@@ -198,92 +237,120 @@ __global__ __launch_bounds__(256) void gemm_kernel(GroupP G) {
         }
     }
     // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
-    float* ep = (float*)smem + wave * 4096;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = 16 * i + (lane & 15);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int c4 = 4 * j + (lane >> 4);
-            *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
-        }
-    }
-    __syncthreads();
+    // VAR 0 stages the wave's whole 64x64 f32 tile (16 KiB per wave); VAR 1 has 32 KiB of LDS and stages 32 rows per pass.
+    constexpr int PASSES = (VAR == 0) ? 1 : 2;
+    constexpr int PROWS = 64 / PASSES;          // rows of the wave tile per pass
+    float* ep = (float*)smem + wave * (PROWS * 64);
     const int mb = m0 + wm * 64, nb = n0 + wn * 64;
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
-    if constexpr (OUT_BF16) {
-        const int cg = lane & 7;
-        const int n = nb + cg * 8;
-        if (n >= p.N) return;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            b0 = *(const f32x4*)(p.bias + n);
-            b1 = *(const f32x4*)(p.bias + n + 4);
-        }
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int r = it * 8 + (lane >> 3);
-            const int m = mb + r;
-            if (m >= p.M) continue;
-            f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
-            f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
-            v0 += b0;
-            v1 += b1;
-            if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
-                const u32x4 h = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
-                v0[0] *= dgelu_erf(bf16lo_to_f32(h[0])); v0[1] *= dgelu_erf(bf16hi_to_f32(h[0]));
-                v0[2] *= dgelu_erf(bf16lo_to_f32(h[1])); v0[3] *= dgelu_erf(bf16hi_to_f32(h[1]));
-                v1[0] *= dgelu_erf(bf16lo_to_f32(h[2])); v1[1] *= dgelu_erf(bf16hi_to_f32(h[2]));
-                v1[2] *= dgelu_erf(bf16lo_to_f32(h[3])); v1[3] *= dgelu_erf(bf16hi_to_f32(h[3]));
-            }
-            const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-            *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-            if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
-                const u32x4 g = {pack_bf16x2(gelu_erf(v0[0]), gelu_erf(v0[1])), pack_bf16x2(gelu_erf(v0[2]), gelu_erf(v0[3])),
-                                 pack_bf16x2(gelu_erf(v1[0]), gelu_erf(v1[1])), pack_bf16x2(gelu_erf(v1[2]), gelu_erf(v1[3]))};
-                *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
+    for (int ps = 0; ps < PASSES; ++ps) {
+        if (ps > 0) __syncthreads();            // previous pass fully read before the staging area is rewritten
+#pragma unroll
+        for (int ii = 0; ii < 4 / PASSES; ++ii) {
+            const int i = ps * (4 / PASSES) + ii;
+            const int r = 16 * ii + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = 4 * j + (lane >> 4);
+                *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
             }
         }
-    } else {
-        if (EPI == MOFO_EPI_F32 && p.atomic) {
+        __syncthreads();
+        const int mp = mb + ps * PROWS;         // first global row of this pass
+        if constexpr (OUT_BF16) {
+            const int cg = lane & 7;
+            const int n = nb + cg * 8;
+            if (n < p.N) {
+                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) {
+                    b0 = *(const f32x4*)(p.bias + n);
+                    b1 = *(const f32x4*)(p.bias + n + 4);
+                }
+#pragma unroll
+                for (int it = 0; it < PROWS / 8; ++it) {
+                    const int r = it * 8 + (lane >> 3);
+                    const int m = mp + r;
+                    if (m >= p.M) continue;
+                    f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
+                    f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
+                    v0 += b0;
+                    v1 += b1;
+                    if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+                        const u32x4 h = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                        v0[0] *= dgelu_erf(bf16lo_to_f32(h[0])); v0[1] *= dgelu_erf(bf16hi_to_f32(h[0]));
+                        v0[2] *= dgelu_erf(bf16lo_to_f32(h[1])); v0[3] *= dgelu_erf(bf16hi_to_f32(h[1]));
+                        v1[0] *= dgelu_erf(bf16lo_to_f32(h[2])); v1[1] *= dgelu_erf(bf16hi_to_f32(h[2]));
+                        v1[2] *= dgelu_erf(bf16lo_to_f32(h[3])); v1[3] *= dgelu_erf(bf16hi_to_f32(h[3]));
+                    }
+                    const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+                    *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                    if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
+                        const u32x4 g = {pack_bf16x2(gelu_erf(v0[0]), gelu_erf(v0[1])), pack_bf16x2(gelu_erf(v0[2]), gelu_erf(v0[3])),
+                                         pack_bf16x2(gelu_erf(v1[0]), gelu_erf(v1[1])), pack_bf16x2(gelu_erf(v1[2]), gelu_erf(v1[3]))};
+                        *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
+                    }
+                }
+            }
+        } else if (EPI == MOFO_EPI_F32 && p.atomic) {
             // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
             const int n = nb + lane;
-            if (n >= p.N) return;
-            float* dst = (float*)p.C + (size_t)mb * p.ldc + n;
-            const int rows = min(64, p.M - mb);
-            for (int r = 0; r < rows; ++r) {
-                atomicAdd(dst, ep[r * 64 + ((((lane >> 2) ^ (r & 15)) << 2) | (lane & 3))]);
-                dst += p.ldc;
+            if (n < p.N) {
+                float* dst = (float*)p.C + (size_t)mp * p.ldc + n;
+                const int rows = min(PROWS, p.M - mp);
+                for (int r = 0; r < rows; ++r) {
+                    atomicAdd(dst, ep[r * 64 + ((((lane >> 2) ^ (r & 15)) << 2) | (lane & 3))]);
+                    dst += p.ldc;
+                }
             }
-            return;
-        }
-        const int c4 = lane & 15;
-        const int n = nb + c4 * 4;
-        if (n >= p.N) return;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) bv = *(const f32x4*)(p.bias + n);
+        } else {
+            const int c4 = lane & 15;
+            const int n = nb + c4 * 4;
+            if (n < p.N) {
+                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+                if (p.bias) bv = *(const f32x4*)(p.bias + n);
 #pragma unroll
-        for (int it = 0; it < 16; ++it) {
-            const int r = it * 4 + (lane >> 4);
-            const int m = mb + r;
-            if (m >= p.M) continue;
-            f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
-            v += bv;
-            size_t orow = m;
-            if constexpr (EPI == MOFO_EPI_RESID_F32) {
-                v += *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
-            } else if constexpr (EPI == MOFO_EPI_POS_F32) {
-                orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
-                v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
+                for (int it = 0; it < PROWS / 4; ++it) {
+                    const int r = it * 4 + (lane >> 4);
+                    const int m = mp + r;
+                    if (m >= p.M) continue;
+                    f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
+                    v += bv;
+                    size_t orow = m;
+                    if constexpr (EPI == MOFO_EPI_RESID_F32) {
+                        v += *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+                    } else if constexpr (EPI == MOFO_EPI_POS_F32) {
+                        orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
+                        v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
+                    }
+                    *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+                }
             }
-            *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
         }
     }
 }
 
+// Which main-loop variant per (layouts, epilogue), from in-step A/B timing on MI355X (ViT-B, B=32; profiles/): the
+// register-double-buffered single-stage form (3 blocks/CU) wins for dgrad (NN) and the plain bf16 NT GEMMs; the
+// two-stage form wins for wgrad (TN: VAR 1 spills at 168 VGPRs) and for the f32 residual / GELU epilogues.
+// MOFO_GEMM_VARIANT=0|1 forces one form for measurements.
+template <int LA, int LB, int EPI>
+int gemm_variant() {
+    static int forced = -2;
+    if (forced == -2) {
+        const char* e = getenv("MOFO_GEMM_VARIANT");
+        forced = e ? (atoi(e) != 0) : -1;
+    }
+    if (forced >= 0) return forced;
+    if (LA == OPL_ROW && LB == OPL_COL) return 1;
+    if (LA == OPL_ROW && LB == OPL_ROW && EPI == MOFO_EPI_BF16) return 1;
+    return 0;
+}
+
 template <int LA, int LB, int EPI>
 int launch(const GroupP& g, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI>), dim3(g.start[g.count]), dim3(256), 0, s, g);
+    if (gemm_variant<LA, LB, EPI>() == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0>), dim3(g.start[g.count]), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1>), dim3(g.start[g.count]), dim3(256), 0, s, g);
     MOFO_CHECK_LAUNCH("mofo_gemm");
     return MOFO_OK;
 }

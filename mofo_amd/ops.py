@@ -14,8 +14,29 @@ from ._lib import (EPI_BF16, EPI_BIAS_GELU, EPI_DGELU_BF16, EPI_F32, EPI_POS_F32
 BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 
 
+_STREAM_OVERRIDE = None   # a torch.cuda.Stream while a launch sequence runs part of its work on a side stream
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    s = _STREAM_OVERRIDE
+    return (s if s is not None else torch.cuda.current_stream()).cuda_stream
+
+
+def use_stream(stream):
+    """route the following C-ABI launches to ``stream`` (a torch.cuda.Stream) or, with None, back to torch's current
+    stream; recorded into launch lists so that a replay switches at the same place"""
+    global _STREAM_OVERRIDE
+    rec = _lib.RECORDER
+    if rec is not None:
+        rec.append(("stream", stream, None, None, 0.0))
+    _STREAM_OVERRIDE = None if _serialize() else stream
+
+
+def _serialize():
+    """while bench.py's FULL per-kernel profiler is on, everything runs on one stream: event pairs then time each kernel
+    alone (comparable with rocprofv3's per-kernel durations) instead of two streams' kernels interleaved"""
+    prof = _lib.PROFILER
+    return prof is not None and prof.only is None
 
 
 def _chk(t, dtype, name, dims=None):
@@ -52,9 +73,9 @@ def _run(name, key, work, *args):
     if prof is None:
         _lib.check(fn(*args, _stream()), name)
     else:
-        prof.begin(key, work)
+        prof.begin(key, work, _STREAM_OVERRIDE)
         _lib.check(fn(*args, _stream()), name)
-        prof.end()
+        prof.end(_STREAM_OVERRIDE)
 
 
 def host_op(f):
@@ -67,19 +88,23 @@ def host_op(f):
 
 def replay(launches):
     """re-issue a recorded launch list on the current stream (pointers and sizes were validated when it was recorded)"""
-    s = _stream()
+    base = torch.cuda.current_stream().cuda_stream
+    s, sobj = base, None
     prof = _lib.PROFILER
     for fn, args, name, key, work in launches:
         if fn is None:
             args()
+        elif fn == "stream":
+            sobj = None if _serialize() else args
+            s = base if sobj is None else sobj.cuda_stream
         elif prof is None:
             rc = fn(*args, s)
             if rc:
                 _lib.check(rc, name)
         else:
-            prof.begin(key, work)
+            prof.begin(key, work, sobj)
             rc = fn(*args, s)
-            prof.end()
+            prof.end(sobj)
             if rc:
                 _lib.check(rc, name)
 

@@ -226,6 +226,7 @@ class PretrainRuntime:
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
         self.segments = self.plan_segments()
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
+        self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
 
@@ -257,8 +258,13 @@ class PretrainRuntime:
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), dxbA=e(M, D), dxbB=e(M, D), dxbC=e(M, D), dxln=e(M, D), dh1=e(M, hid), dqkv=e(M, 3 * D),
-                  dao=e(M, D), delta=e(B * H * n, dt=F32))
+        # the weight-gradient GEMMs of a block run on a side stream while the next blocks' activation-gradient chain
+        # proceeds, so everything they read (dh1, dx_mid copy, dqkv, dx_out copy) is double / triple buffered
+        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), ring=[e(M, D), e(M, D), e(M, D)], dxln=e(M, D),
+                  sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(2)],
+                  dao=e(M, D), delta=e(B * H * n, dt=F32),
+                  ready=[torch.cuda.Event() for _ in range(2)] if self.dev.type == "cuda" else None,
+                  done=[torch.cuda.Event() for _ in range(2)] if self.dev.type == "cuda" else None, used=[False, False])
 
     def ws(self, B: int, n_vis: Optional[int] = None, N: Optional[int] = None) -> NS:
         """workspace for batch size B (and visible-token count n_vis); allocated once, reused every step"""
@@ -345,24 +351,42 @@ class PretrainRuntime:
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
 
-    def _block_bwd(self, W, L, S, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
+    def _block_bwd(self, W, L, S, k, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
         """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in.  dx_in may alias dx_out;
-        dxb_in must NOT alias dxb_out (the deferred weight-gradient launch at the end still reads dxb_out)."""
+        dxb_in must NOT alias dxb_out.  ``k`` = parity of the block: selects the scratch set whose buffers the block's
+        deferred weight-gradient launch (side stream) reads while the following block already runs."""
         scale = 64 ** -0.5
         D = x_in.shape[1]
+        T = S.sets[k]
+        side = self.side
+        if S.used[k]:   # the weight-gradient launch that last read this scratch set must be finished before it is rewritten
+            ops.host_op(lambda ev=S.done[k]: torch.cuda.current_stream().wait_event(ev))
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
-        ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, S.dh1, aux=L.h1)
-        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dh1, W.fc1, S.dxln)
-        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dx_out, S.dxB, S.dxbB, W.g_ln2w, W.g_ln2b)
+        ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, T.dh1, aux=L.h1)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dh1, W.fc1, S.dxln)
+        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dx_out, S.dxB, T.dxbB, W.g_ln2w, W.g_ln2b)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
-        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dxbB, W.proj, S.dao)
-        ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, S.dqkv, S.delta)
-        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, S.dqkv, W.qkv, S.dxln)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
+        ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
         ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
-        # parameter gradients of the whole block, off the activation-gradient chain
-        # (weights + biases; the bias gradients are column sums of the same dY operands, fused into the GEMMs)
-        self._wgrad_group([(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (S.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
-                           (S.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (S.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))])
+        # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
+        # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
+        ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
+        ops.use_stream(side)
+        ops.host_op(lambda ev=S.ready[k]: side.wait_event(ev))
+        self._wgrad_group([(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
+                           (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))])
+        ops.host_op(lambda ev=S.done[k]: ev.record(side))
+        ops.use_stream(None)
+        S.used[k] = True
+
+    def _join_side(self, S):
+        """main stream waits for every outstanding side-stream weight-gradient launch of this scratch"""
+        for k in range(2):
+            if S.used[k]:
+                ops.host_op(lambda ev=S.done[k]: torch.cuda.current_stream().wait_event(ev))
+                S.used[k] = False
 
     def plan_segments(self, blocks_per_bucket: int = 3) -> List[Tuple[int, int]]:
         """Contiguous ranges of the flat gradient buffer in the order backward completes them (the data-parallel
@@ -434,20 +458,23 @@ class PretrainRuntime:
     def encoder_backward(self, w: NS, d_out_bf16: torch.Tensor):
         d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
-        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, S.dxA, S.dxbA,
+        S.used = [False, False]
+        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, S.dxA, S.ring[0],
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
         cnt = 0
-        cur, nxt = S.dxbA, S.dxbC
+        j = 0
         for i in range(d.enc_depth - 1, -1, -1):
             x_in = w.enc[i - 1].x_out if i > 0 else w.enc_x0
-            self._block_bwd(self.encW[i], w.enc[i], S, x_in, S.dxA, cur, S.dxA, nxt, w.B, w.n_vis, d.enc_heads)
-            cur, nxt = nxt, cur
+            self._block_bwd(self.encW[i], w.enc[i], S, j & 1, x_in, S.dxA, S.ring[j % 3], S.dxA, S.ring[(j + 1) % 3], w.B, w.n_vis, d.enc_heads)
+            j += 1
             cnt += 1
             if cnt == 3 and i > 0:  # gradient buckets of three encoder blocks (~85 MB fp32 at ViT-B)
+                self._join_side(S)
                 self._seg(seg)
                 seg, cnt = seg + 1, 0
-        self._wgrad(cur, w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
+        self._wgrad(S.ring[j % 3], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
+        self._join_side(S)
         self._seg(seg)
 
     # ------------------------------------------------------------------ bridge
@@ -484,14 +511,16 @@ class PretrainRuntime:
         self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"))
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
-        ops.host_op(lambda: (S.dxA.zero_(), S.dxbA.zero_()))
-        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, S.dxA, S.dxbA,
+        S.used = [False, False]
+        ops.host_op(lambda: (S.dxA.zero_(), S.ring[0].zero_()))
+        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, S.dxA, S.ring[0],
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
-        cur, nxt = S.dxbA, S.dxbC
+        j = 0
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
-            self._block_bwd(self.decW[i], w.dec[i], S, x_in, S.dxA, cur, S.dxA, nxt, w.B, w.N, d.dec_heads)
-            cur, nxt = nxt, cur
+            self._block_bwd(self.decW[i], w.dec[i], S, j & 1, x_in, S.dxA, S.ring[j % 3], S.dxA, S.ring[(j + 1) % 3], w.B, w.N, d.dec_heads)
+            j += 1
+        self._join_side(S)
         return S.dxA
 
     # ------------------------------------------------------------------ whole model
