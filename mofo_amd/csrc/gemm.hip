@@ -58,12 +58,12 @@ __device__ __forceinline__ int col_key(int krow) { return (krow & 3) | (((krow >
 
 // Issue the LDS-DMA loads of one operand tile.  `dim` = extent of the non-reduction index, `kend` = end of the
 // reduction range of this block.
-template <int LAYOUT>
+template <int LAYOUT, int NI>   // NI wave-instructions per wave: 4 for a 128-row (ROW) / 128-column (COL) tile, 2 for 64 rows
 __device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int ld, int dim, int d0, int k0, int kend,
                                            unsigned char* lds_tile, int wave, int lane) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int i = wave * 4 + j;  // wave-instruction index 0..15, 1 KiB each
+    for (int j = 0; j < NI; ++j) {
+        const int i = wave * NI + j;  // wave-instruction index, 1 KiB each
         const bf16_t* src;
         if constexpr (LAYOUT == OPL_ROW) {
             const int rl = 8 * i + (lane >> 3);
@@ -111,9 +111,15 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
 // double-buffering: all fragments of tile t are read into VGPRs, barrier, tile t+1's LDS-DMA is issued into the same
 // LDS buffer and flies while the 32 MFMAs of tile t run from registers.  More resident blocks per CU let one block's
 // (HBM-bound) epilogue overlap another's main loop; the model's short reductions (K = 384..3072) need that.
-template <int LA, int LB, int EPI, int VAR>
+// MI = 16-row MFMA sub-tiles per wave in M: MI 4 -> 128x128 block tile, MI 2 -> 64x128 (twice the blocks for the
+// shapes whose 128x128 tiling gives fewer blocks than the chip has CUs, e.g. M = 5120, N = 768: 240 -> 480).
+template <int LA, int LB, int EPI, int VAR, int MI>
 __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[(VAR == 0 ? 4 : 2) * TILE_BYTES];  // [buf][A|B]
+    static_assert(MI == 4 || (MI == 2 && LA == OPL_ROW), "64-row tiles are built for the ROW A operand (NT / NN)");
+    constexpr int BMT = 32 * MI;                       // block tile rows
+    constexpr int A_BYTES = BMT * 64 * 2;              // A stage bytes (ROW: [BMT][64] ; COL: [64][128])
+    constexpr int STG = A_BYTES + TILE_BYTES;          // one stage = A tile + B tile
+    __shared__ __attribute__((aligned(16))) unsigned char smem[(VAR == 0 ? 2 : 1) * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     int gi = 0;
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     // XCD-aware remap (8 XCDs, private L2s): blocks b and b+8 share an XCD, so give each XCD a contiguous
     // run of tiles with n fastest; the B panel (weights) and one A row-panel then stay L2-resident per XCD.
     const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int tiles = tiles_n * ((p.M + BMT - 1) / BMT);
     const int nwg = G.start[gi + 1] - G.start[gi];
     int wg = blockIdx.x - G.start[gi];
     {
@@ -134,31 +140,31 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     }
     const int split = wg / tiles;
     wg -= split * tiles;
-    const int m0 = (wg / tiles_n) * BM, n0 = (wg % tiles_n) * BN;
+    const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
 
-    f32x4 acc[4][4];
+    f32x4 acc[MI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     // bias gradient on the wgrad GEMM: one extra MFMA per m-subtile against an all-ones fragment gives sum_k A[k,m]
     // (replaces a separate column-sum kernel that re-read every dY).  Only the first n-tile's wn==0 waves do it.
     constexpr bool CAN_COLSUM = (LA == OPL_COL && LB == OPL_COL && EPI == MOFO_EPI_F32);
     const bool do_colsum = CAN_COLSUM && p.colsum != nullptr && n0 == 0 && wn == 0;
-    f32x4 accb[4];
+    f32x4 accb[MI];
     bf16x8 ones;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < MI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
     auto stage = [&](int t, int buf) {
-        unsigned char* ta = smem + buf * 2 * TILE_BYTES;
-        stage_tile<LA>(p.A, p.lda, p.M, m0, kbeg + t * BK, kend, ta, wave, lane);
-        stage_tile<LB>(p.B, p.ldb, p.N, n0, kbeg + t * BK, kend, ta + TILE_BYTES, wave, lane);
+        unsigned char* ta = smem + buf * STG;
+        stage_tile<LA, MI>(p.A, p.lda, p.M, m0, kbeg + t * BK, kend, ta, wave, lane);
+        stage_tile<LB, 4>(p.B, p.ldb, p.N, n0, kbeg + t * BK, kend, ta + A_BYTES, wave, lane);
     };
 
     if (nk > 0) stage(0, 0);
@@ -168,24 +174,24 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
         int cur = 0;
         for (int t = 0; t < nk; ++t) {
             if (t + 1 < nk) stage(t + 1, cur ^ 1);
-            const unsigned char* ta = smem + cur * 2 * TILE_BYTES;
-            const unsigned char* tb = ta + TILE_BYTES;
+            const unsigned char* ta = smem + cur * STG;
+            const unsigned char* tb = ta + A_BYTES;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                bf16x8 af[4], bfr[4];
+                bf16x8 af[MI], bfr[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[i] = read_frag<LA>(ta, wm * 64 + 16 * i, ks, lane);
+                for (int i = 0; i < MI; ++i) af[i] = read_frag<LA>(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bfr[i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
                 if constexpr (CAN_COLSUM) {
                     if (do_colsum) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
+                        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[i], accb[i], 0, 0, 0);
                     }
                 }
             }
@@ -195,13 +201,13 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
         }
     } else {
         const unsigned char* ta = smem;
-        const unsigned char* tb = smem + TILE_BYTES;
+        const unsigned char* tb = smem + A_BYTES;
         for (int t = 0; t < nk; ++t) {
-            bf16x8 af[2][4], bfr[2][4];
+            bf16x8 af[2][MI], bfr[2][4];
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) af[ks][i] = read_frag<LA>(ta, wm * 64 + 16 * i, ks, lane);
+                for (int i = 0; i < MI; ++i) af[ks][i] = read_frag<LA>(ta, wm * (16 * MI) + 16 * i, ks, lane);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) bfr[ks][i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
             }
@@ -211,14 +217,14 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
                 if constexpr (CAN_COLSUM) {
                     if (do_colsum) {
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
+                        for (int i = 0; i < MI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[ks][i], accb[i], 0, 0, 0);
                     }
                 }
             }
@@ -230,8 +236,8 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     if constexpr (CAN_COLSUM) {
         if (do_colsum && lane < 16) {   // D[n][m]: every row n holds the same sum; lanes 0..15 hold m = 16 i + lane in element 0
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = m0 + wm * 64 + 16 * i + lane;
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (16 * MI) + 16 * i + lane;
                 if (m < p.M && !(m >= p.colsum_skip_lo && m < p.colsum_skip_hi)) atomicAdd(p.colsum + m, accb[i][0]);
             }
         }
@@ -239,16 +245,18 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
     // VAR 0 stages the wave's whole 64x64 f32 tile (16 KiB per wave); VAR 1 has 32 KiB of LDS and stages 32 rows per pass.
     constexpr int PASSES = (VAR == 0) ? 1 : 2;
-    constexpr int PROWS = 64 / PASSES;          // rows of the wave tile per pass
+    constexpr int WROWS = 16 * MI;              // rows of the wave tile
+    constexpr int PROWS = WROWS / PASSES;       // ... per pass
+    static_assert(4 * PROWS * 64 * 4 <= (VAR == 0 ? 2 : 1) * STG, "epilogue staging must fit the main-loop LDS");
     float* ep = (float*)smem + wave * (PROWS * 64);
-    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    const int mb = m0 + wm * WROWS, nb = n0 + wn * 64;
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
         if (ps > 0) __syncthreads();            // previous pass fully read before the staging area is rewritten
 #pragma unroll
-        for (int ii = 0; ii < 4 / PASSES; ++ii) {
-            const int i = ps * (4 / PASSES) + ii;
+        for (int ii = 0; ii < MI / PASSES; ++ii) {
+            const int i = ps * (MI / PASSES) + ii;
             const int r = 16 * ii + (lane & 15);
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -348,16 +356,26 @@ int gemm_variant() {
 }
 
 template <int LA, int LB, int EPI>
-int launch(const GroupP& g, hipStream_t s) {
-    if (gemm_variant<LA, LB, EPI>() == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0>), dim3(g.start[g.count]), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1>), dim3(g.start[g.count]), dim3(256), 0, s, g);
+int launch(const GroupP& g, int mi, hipStream_t s) {
+    const int var = gemm_variant<LA, LB, EPI>();
+    const dim3 grid(g.start[g.count]), block(256);
+    if constexpr (LA == OPL_ROW) {
+        if (mi == 2) {
+            if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 2>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 2>), grid, block, 0, s, g);
+            MOFO_CHECK_LAUNCH("mofo_gemm");
+            return MOFO_OK;
+        }
+    }
+    if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
+    else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
     MOFO_CHECK_LAUNCH("mofo_gemm");
     return MOFO_OK;
 }
 
 }  // namespace
 
-static int fill_problem(const mofo_gemm_args* a, GemmP& p, int& blocks) {
+static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) {
     if (!a->A || !a->B || !a->C) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: non-positive dims %d %d %d", a->M, a->N, a->K);
     const int op = a->op, epi = a->epilogue;
@@ -387,12 +405,12 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int& blocks) {
     p.colsum_skip_lo = a->colsum_skip_lo;
     p.colsum_skip_hi = a->colsum_skip_hi;
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
-    blocks = ceil_div(a->M, BM) * ceil_div(a->N, BN) * splits;
+    blocks = ceil_div(a->M, bm) * ceil_div(a->N, BN) * splits;
     return MOFO_OK;
 }
 
-static int dispatch(int op, int epi, const GroupP& g, hipStream_t s) {
-#define GO(LA, LB, E) return launch<LA, LB, E>(g, s)
+static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
+#define GO(LA, LB, E) return launch<LA, LB, E>(g, mi, s)
     if (op == MOFO_GEMM_NT) {
         switch (epi) {
             case MOFO_EPI_BF16: GO(OPL_ROW, OPL_ROW, MOFO_EPI_BF16);
@@ -422,10 +440,18 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
     GroupP g;
     g.count = count;
     g.start[0] = 0;
+    // 64-row tiles when 128x128 tiling would leave the 256 CUs with fewer than ~1.5 blocks each (NT / NN only)
+    int mi = 4;
+    if (a[0].op != MOFO_GEMM_TN) {
+        long long t128 = 0;
+        for (int i = 0; i < count; ++i) t128 += (long long)ceil_div(a[i].M, 128) * ceil_div(a[i].N, BN);
+        const char* e = getenv("MOFO_GEMM_MI");
+        if (e ? atoi(e) == 2 : t128 < 400) mi = 2;
+    }
     for (int i = 0; i < count; ++i) {
         if (a[i].op != a[0].op || a[i].epilogue != a[0].epilogue) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: problems must share op and epilogue");
         int blocks = 0;
-        const int rc = fill_problem(&a[i], g.p[i], blocks);
+        const int rc = fill_problem(&a[i], g.p[i], 32 * mi, blocks);
         if (rc) return rc;
         g.start[i + 1] = g.start[i] + blocks;
     }
@@ -433,7 +459,7 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
         g.p[i] = g.p[0];
         g.start[i + 1] = g.start[count];
     }
-    return dispatch(a[0].op, a[0].epilogue, g, (hipStream_t)stream);
+    return dispatch(a[0].op, a[0].epilogue, g, mi, (hipStream_t)stream);
 }
 
 extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
