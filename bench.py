@@ -84,7 +84,8 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
+    force_dp = os.environ.get("MOFO_FORCE_DP") == "1" and "MASTER_ADDR" in os.environ
+    if world > 1 or force_dp:
         dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
 
     from mofo_amd import _lib, optim_factory, utils
@@ -104,7 +105,7 @@ def main():
     mask_dev = mask_u8.clone()
     _Args.lr = 1.5e-4 * (B * world) / 256                          # run_mae_pretraining.py:217
     opt = optim_factory.create_optimizer(_Args, model)
-    wrapped = DataParallel(model) if world > 1 else model
+    wrapped = DataParallel(model) if (world > 1 or force_dp) else model
     scaler = utils.NativeScalerWithGradNormCount()
     total_steps = args.steps + args.warmup
     lr_sched = utils_quiet(utils.cosine_scheduler, _Args.lr, 1e-5, 1, total_steps + 1, warmup_epochs=0)
@@ -206,7 +207,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force_dp:
         dist.destroy_process_group()
 
 

@@ -87,12 +87,15 @@ __device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int&
 
 // ------------------------------------------------------------------------------------------------ forward
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
-template <int NW, int MODE>
+// WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
+// and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
+template <int NW, int MODE, bool WHOLE>
 __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
                                                           bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * 2 * TILE];
+    constexpr int NBUF = WHOLE ? 5 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     int xb, b, h;
     if (!decode_block(nx, G, H, xb, b, h)) return;
@@ -149,13 +152,21 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             *(u32x4*)(d + TILE) = vreg;
         }
     };
-    gload(0);
-    lwrite(0);
-    __syncthreads();
-    if (nkt > 1) gload(1);
+    if constexpr (WHOLE) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            gload(kt);
+            lwrite(kt);
+        }
+        __syncthreads();
+    } else {
+        gload(0);
+        lwrite(0);
+        __syncthreads();
+        if (nkt > 1) gload(1);
+    }
 
     for (int kt = 0; kt < nkt; ++kt) {
-        const unsigned char* Kt = smem + (kt & 1) * 2 * TILE;
+        const unsigned char* Kt = smem + (WHOLE ? kt : (kt & 1)) * 2 * TILE;
         const unsigned char* Vt = Kt + TILE;
         f32x16 s = zero16();
 #pragma unroll
@@ -213,9 +224,11 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 1, lane), f0, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 1, lane), f1, o1, 0, 0, 0);
         }
-        if (kt + 1 < nkt) lwrite((kt + 1) & 1);
-        __syncthreads();
-        if (kt + 2 < nkt) gload(kt + 2);
+        if constexpr (!WHOLE) {
+            if (kt + 1 < nkt) lwrite((kt + 1) & 1);
+            __syncthreads();
+            if (kt + 2 < nkt) gload(kt + 2);
+        }
     }
 
     if (!qvalid) return;
@@ -230,14 +243,15 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int NW>
+template <int NW, bool WHOLE>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int lddqkv) {
     // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
     constexpr int BUF = 2 * TILE + 256;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * BUF];
+    constexpr int NBUF = WHOLE ? 5 : 2;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     int xb, b, h;
     if (!decode_block(nx, G, H, xb, b, h)) return;
@@ -286,13 +300,21 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             if (tid < 64) *(float*)(smem + buf * BUF + 2 * TILE + tid * 4) = sreg;
         }
     };
-    gload(0);
-    lwrite(0);
-    __syncthreads();
-    if (nqt > 1) gload(1);
+    if constexpr (WHOLE) {
+        for (int qt = 0; qt < nqt; ++qt) {
+            gload(qt);
+            lwrite(qt);
+        }
+        __syncthreads();
+    } else {
+        gload(0);
+        lwrite(0);
+        __syncthreads();
+        if (nqt > 1) gload(1);
+    }
 
     for (int qt = 0; qt < nqt; ++qt) {
-        const unsigned char* Qt = smem + (qt & 1) * BUF;
+        const unsigned char* Qt = smem + (WHOLE ? qt : (qt & 1)) * BUF;
         const unsigned char* Ot = Qt + TILE;
         const float* Lt = (const float*)(Qt + 2 * TILE);
         const float* Dt = Lt + 32;
@@ -324,9 +346,11 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
-        if (qt + 1 < nqt) lwrite((qt + 1) & 1);
-        __syncthreads();
-        if (qt + 2 < nqt) gload(qt + 2);
+        if constexpr (!WHOLE) {
+            if (qt + 1 < nqt) lwrite((qt + 1) & 1);
+            __syncthreads();
+            if (qt + 2 < nqt) gload(qt + 2);
+        }
     }
     if (ki >= N) return;
     bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
@@ -343,8 +367,9 @@ int pick_nw(int N) {
 
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE)                                                                                              \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,     \
+#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true); } else { LAUNCH_Q_(NW, MODE, false); } } while (0)
+#define LAUNCH_Q_(NW, MODE, WH)                                                                                         \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
                        (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
 
@@ -391,8 +416,9 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
         default: LAUNCH_Q(4, 1); break;
     }
     MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
-#define LAUNCH_KV(NW)                                                                                                  \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,       \
+#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true); } else { LAUNCH_KV_(NW, false); } } while (0)
+#define LAUNCH_KV_(NW, WH)                                                                                             \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
     switch (nw) {

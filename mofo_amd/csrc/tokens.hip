@@ -91,26 +91,35 @@ __global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict_
     }
 }
 
-// blockDim = D/4 rounded up to 64; each block handles RB consecutive rows of dx_full [B*N, D]
-constexpr int RB = 32;
-__global__ void assemble_bwd_kernel(const float* __restrict__ dx, int N, int n_vis, int D, int rows,
-                                    bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {
-    const int c = threadIdx.x * 4;
-    if (c >= D) return;
+// 256 threads = CT column threads (one float4 each, CT = D/4 rounded up to a power-of-two divisor of 256) x RL row lanes;
+// a block covers RB rows; the masked rows' column sums are reduced over the row lanes in LDS, one atomic per column.
+constexpr int RB = 64;
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, int N, int n_vis, int D, int rows, int ct,
+                                                           bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {
+    __shared__ f32x4 red[256];
+    const int cthr = threadIdx.x % ct, rl = threadIdx.x / ct, nrl = 256 / ct;
+    const int c = cthr * 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int r0 = blockIdx.x * RB;
-    for (int r = r0; r < min(rows, r0 + RB); ++r) {
-        const int b = r / N, j = r - b * N;
-        const f32x4 v = *(const f32x4*)(dx + (size_t)r * D + c);
-        if (j < n_vis) {
-            u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-            *(u32x2*)(d_e2d + ((size_t)b * n_vis + j) * D + c) = pk;
-        } else {
-            acc += v;
+    if (c < D) {
+        for (int r = r0 + rl; r < min(rows, r0 + RB); r += nrl) {
+            const int b = r / N, j = r - b * N;
+            const f32x4 v = *(const f32x4*)(dx + (size_t)r * D + c);
+            if (j < n_vis) {
+                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                *(u32x2*)(d_e2d + ((size_t)b * n_vis + j) * D + c) = pk;
+            } else {
+                acc += v;
+            }
         }
     }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0 && c < D) {
+        for (int k = 1; k < nrl; ++k) acc += red[k * ct + cthr];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) atomicAdd(d_mask_token + c + e, acc[e]);
+        for (int e = 0; e < 4; ++e) atomicAdd(d_mask_token + c + e, acc[e]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- column sums
@@ -182,11 +191,13 @@ extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, 
 extern "C" int mofo_assemble_bwd(const float* dx_full, int B, int N, int n_vis, int D, void* d_e2d, float* d_mask_token,
                                  void* stream) {
     if (!dx_full || !d_e2d || !d_mask_token) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: null pointer");
-    if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || D > 4096) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: bad sizes");
+    if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || D > 1024) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: bad sizes");
     const int rows = B * N;
-    const int threads = ceil_div(D / 4, 64) * 64;
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(ceil_div(rows, RB)), dim3(threads), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
-                       rows, (bf16_t*)d_e2d, d_mask_token);
+    int ct = 1;
+    while (ct * 4 < D) ct *= 2;     // column threads: power of two >= D/4
+    if (ct > 256) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_assemble_bwd: D=%d too wide", D);
+    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(ceil_div(rows, RB)), dim3(256), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
+                       rows, ct, (bf16_t*)d_e2d, d_mask_token);
     MOFO_CHECK_LAUNCH("mofo_assemble_bwd");
     return MOFO_OK;
 }

@@ -18,7 +18,10 @@ class GradSync:
         self.model = model
         self.pg = process_group
         self.handles: List = []
-        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(process_group) > 1
+        # a one-rank group is a no-op exchange; MOFO_FORCE_DP=1 keeps it on so the plumbing can be exercised on one GPU
+        import os
+        ws = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 0
+        self.enabled = ws > 1 or (ws == 1 and os.environ.get("MOFO_FORCE_DP") == "1")
         self.launched: List[tuple] = []
 
     def install(self):

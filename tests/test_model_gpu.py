@@ -238,3 +238,81 @@ def test_bad_mask_is_reported(dev):
     model.forward_loss(x, mask.to(dev))
     with pytest.raises(RuntimeError, match="visible tokens"):
         model.check_status()
+
+
+def test_bb_engine_and_checkpoint_roundtrip(dev, tmp_path):
+    """train_one_epoch_BB (batches carry bboxes, masks from TubeMaskingGenerator_BB) for two steps on the tiny config
+    against the oracle's AdamW trajectory; then utils.save_model / auto_load_model restore model + optimizer exactly."""
+    import types
+    from mofo_amd import engine_for_pretraining as eng
+    from mofo_amd import optim_factory, utils
+    from mofo_amd.masking_generator import TubeMaskingGenerator_BB
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    model, P = _build(cfg, "xavier", dev)
+    x = O.keyed_clips(2, cfg)
+    np.random.seed(3)
+    gen = TubeMaskingGenerator_BB((8, 2, 2), 0.75, 0.75)
+    boxes = [np.tile(np.array([0, 0, 20, 20]), (16, 1)), np.tile(np.array([10, 5, 30, 31]), (16, 1))]
+    masks = torch.from_numpy(np.stack([gen(b) for b in boxes]))
+    assert masks.sum(1).tolist() == [24.0, 24.0]
+    bbox = torch.from_numpy(np.stack(boxes))
+    opt = optim_factory.create_optimizer(_Args, model)
+    stats = eng.train_one_epoch_BB(model, [(x, bbox, masks), (x, bbox, masks)], opt, dev, 0, utils.NativeScalerWithGradNormCount(),
+                                   max_norm=None, start_steps=0)
+    st = O.AdamWState()
+    ref = [O.train_step(x, masks.bool(), P, cfg, st)[0] for _ in range(2)]
+    assert stats["loss"] == pytest.approx(sum(ref) / 2, rel=1e-3)
+    args = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="", start_epoch=0)
+    utils.save_model(args, 7, model, model, opt, utils.NativeScalerWithGradNormCount())
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint-7.pth"), weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args"} and list(ck["model"]) == list(P)   # reference schema
+    model2, _ = _build(cfg, "small", dev)
+    opt2 = optim_factory.create_optimizer(_Args, model2)
+    utils.auto_load_model(args, model2, model2, opt2, utils.NativeScalerWithGradNormCount())
+    assert args.start_epoch == 8
+    for (n1, p1), (n2, p2) in zip(model.state_dict().items(), model2.state_dict().items()):
+        assert n1 == n2 and torch.equal(p1, p2)
+    assert opt2._step == opt._step and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    # the two replicas continue identically
+    xm, mm = x.to(dev), masks.bool().to(dev)
+    l1 = model.forward_loss(xm, mm)
+    l2 = model2.forward_loss(xm, mm)
+    assert float(l1) == float(l2)
+
+
+def test_gradient_sync_on_one_rank_rccl(dev):
+    """exercise the data-parallel plumbing on ONE GPU: RCCL ('nccl') group of size 1, gradient ranges all-reduced
+    asynchronously from inside the (replayed) backward launch list, joined before the optimizer.  Results must equal
+    the plain single-GPU step."""
+    import torch.distributed as dist
+    from mofo_amd import optim_factory, utils
+    from mofo_amd.dist import DataParallel
+    from oracle import pretrain_oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", MOFO_FORCE_DP="1")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        cfg = O.TINY
+        x = O.keyed_clips(2, cfg).to(dev)
+        mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool().to(dev)
+        losses = {}
+        for tag in ("plain", "dp"):
+            model, _ = _build(cfg, "xavier", dev)
+            opt = optim_factory.create_optimizer(_Args, model)
+            wrapped = DataParallel(model) if tag == "dp" else model
+            if tag == "dp":
+                assert wrapped.sync.enabled and model.runtime().segment_hook is not None
+            scaler = utils.NativeScalerWithGradNormCount()
+            out = []
+            for _ in range(3):                     # step 0 records the launch lists, steps 1-2 replay them
+                loss = wrapped.forward_loss(x, mask)
+                out.append(float(loss))
+                opt.zero_grad()
+                scaler(loss, opt)
+            if tag == "dp":
+                assert len(wrapped.sync.handles) == 0      # joined
+            losses[tag] = out
+        np.testing.assert_allclose(losses["dp"], losses["plain"], rtol=1e-6)
+    finally:
+        dist.destroy_process_group()
+        os.environ.pop("MOFO_FORCE_DP", None)
