@@ -11,12 +11,18 @@
 // K/V (or Q/dO) tiles of 32 rows are register-staged into a 2-deep LDS ring: one barrier per tile.
 #include "common.h"
 #include "../../include/mofo_hip.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int HD = 64;
-constexpr int RS = 144;              // LDS row stride in bytes: 128 B of data + 16 B pad (b128 row reads conflict-free)
+constexpr int RS = 128;              // LDS row stride in bytes (no padding)
 constexpr int TILE = 32 * RS;        // one 32-row tile
+// One LDS image serves BOTH the row reads (ds_read_b128, MFMA operand = rows of the tile) and the transposed reads
+// (ds_read_b64_tr_b16, MFMA operand = columns): 16-B chunk c of row r is stored at chunk c ^ swz(r),
+// swz(r) = ((r>>1)&1)<<2 | (r>>2)&3.  Brute-force checked conflict-free for every fragment of both kinds (the padded
+// 144-B rows were 2-way conflicted on the transposed reads: 23-26 % of the LDS cycles, and these kernels are LDS-bound).
+__device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 constexpr float NEG_BIG = -1.0e30f;
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -32,16 +38,20 @@ __device__ __forceinline__ f32x16 zero16() {
 
 // A operand = rows of a [32][64] LDS tile: A[row = lane&31][k = 16 ks + 8 hh + j]
 __device__ __forceinline__ bf16x8 row_frag(const unsigned char* tile, int ks, int lane) {
-    return *(const bf16x8*)(tile + (lane & 31) * RS + (16 * ks + 8 * (lane >> 5)) * 2);
+    const int r = lane & 31;
+    return *(const bf16x8*)(tile + r * RS + (((2 * ks + (lane >> 5)) ^ swz(r)) << 4));
 }
 
 // A operand = TRANSPOSE of a [32 seq][64 d] LDS tile for k-step s2 (16 seq rows) and d-tile dt (32 d):
 // A[row = d = 32 dt + (lane&31)][slot (hh, j)] = tile[seq = 16 s2 + 8 (j>>2) + 4 hh + (j&3)][d]
 __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int s2, int dt, int lane) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hh = lane >> 5;
-    const unsigned char* a0 = tile + (16 * s2 + 4 * hh + q) * RS + (32 * dt + 16 * (g & 1) + 4 * pp) * 2;
+    const int r0 = 16 * s2 + 4 * hh + q, r1 = r0 + 8;
+    const int chunk = 4 * dt + 2 * (g & 1) + (pp >> 1), sub = (pp & 1) * 8;
+    const unsigned char* a0 = tile + r0 * RS + ((chunk ^ swz(r0)) << 4) + sub;
+    const unsigned char* a1 = tile + r1 * RS + ((chunk ^ swz(r1)) << 4) + sub;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0 + 8 * RS));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
     s16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -89,8 +99,8 @@ __device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int&
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
 // and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
-template <int NW, int MODE, bool WHOLE>
-__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
+template <int NW, int MODE, bool WHOLE, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
                                                           bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
@@ -147,7 +157,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     };
     auto lwrite = [&](int buf) {
         if (tid < 256) {
-            unsigned char* d = smem + buf * 2 * TILE + (tid >> 3) * RS + (tid & 7) * 16;
+            unsigned char* d = smem + buf * 2 * TILE + (tid >> 3) * RS + (((tid & 7) ^ swz(tid >> 3)) << 4);
             *(u32x4*)d = kreg;
             *(u32x4*)(d + TILE) = vreg;
         }
@@ -243,8 +253,8 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int NW, bool WHOLE>
-__global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
+template <int NW, bool WHOLE, int OCC>
+__global__ __launch_bounds__(NW * 64, OCC) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int lddqkv) {
@@ -294,7 +304,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     };
     auto lwrite = [&](int buf) {
         if (tid < 256) {
-            unsigned char* d = smem + buf * BUF + (tid >> 3) * RS + (tid & 7) * 16;
+            unsigned char* d = smem + buf * BUF + (tid >> 3) * RS + (((tid & 7) ^ swz(tid >> 3)) << 4);
             *(u32x4*)d = qreg;
             *(u32x4*)(d + TILE) = oreg;
             if (tid < 64) *(float*)(smem + buf * BUF + 2 * TILE + tid * 4) = sreg;
@@ -359,17 +369,30 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
 }
 
 int pick_nw(int N) {
+    static int forced = -1;
+    if (forced < 0) {
+        const char* e = getenv("MOFO_ATTN_NW");
+        forced = e ? atoi(e) : 0;
+    }
     const int t = (N + 31) / 32;  // 32-row wave tiles
-    if (t % 7 == 0) return 7;
-    if (t % 5 == 0) return 5;
-    return 4;
+    if (t <= 5) return 5;         // short sequences: one block per (clip, head)
+    if (forced == 4 || forced == 7) return forced;
+    return 4;                     // 3 blocks/CU by waves; measured 3 % faster than 7-wave blocks even with a 6 % ragged tail
+}
+int pick_occ() {
+    static int v = -1;
+    if (v < 0) {
+        const char* e = getenv("MOFO_ATTN_OCC");
+        v = e ? atoi(e) : 0;
+    }
+    return v;
 }
 
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true); } else { LAUNCH_Q_(NW, MODE, false); } } while (0)
-#define LAUNCH_Q_(NW, MODE, WH)                                                                                         \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
+#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, 1); } else if (pick_occ() == 3) { LAUNCH_Q_(NW, MODE, false, 3); } else { LAUNCH_Q_(NW, MODE, false, 1); } } while (0)
+#define LAUNCH_Q_(NW, MODE, WH, OC)                                                                                     \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, OC>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
                        (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
 
@@ -416,9 +439,9 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
         default: LAUNCH_Q(4, 1); break;
     }
     MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
-#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true); } else { LAUNCH_KV_(NW, false); } } while (0)
-#define LAUNCH_KV_(NW, WH)                                                                                             \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
+#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, 1); } else if (pick_occ() == 3) { LAUNCH_KV_(NW, false, 3); } else { LAUNCH_KV_(NW, false, 1); } } while (0)
+#define LAUNCH_KV_(NW, WH, OC)                                                                                         \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, OC>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
     switch (nw) {
