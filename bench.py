@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE configs[1]/[2]: 32)")
+    ap.add_argument("--mask", choices=["tube", "bb"], default="tube",
+                    help="tube: TubeMaskingGenerator 0.9 (configs 1/2); bb: MOFO motion-bounding-box masks, 75%% in-box (config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing (roofline block)")
@@ -91,7 +93,7 @@ def main():
     from mofo_amd import _lib, optim_factory, utils
     from mofo_amd import modeling_pretrain as mp
     from mofo_amd.dist import DataParallel
-    from mofo_amd.masking_generator import TubeMaskingGenerator
+    from mofo_amd.masking_generator import TubeMaskingGenerator, TubeMaskingGenerator_BB
 
     torch.manual_seed(0)           # identical random-init replica on every rank (DDP would broadcast rank 0's)
     model = mp.pretrain_videomae_base_patch16_224(decoder_depth=4).to(dev)
@@ -100,8 +102,17 @@ def main():
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # seed = base + rank, run_mae_pretraining.py:166
     clips.normal_(generator=gen)
     np.random.seed(rank)
-    mgen = TubeMaskingGenerator((8, 14, 14), 0.9)
-    mask_u8.copy_(torch.from_numpy(np.stack([mgen() for _ in range(B)]).astype(np.uint8)))
+    if args.mask == "tube":
+        mgen = TubeMaskingGenerator((8, 14, 14), 0.9)
+        masks = [mgen() for _ in range(B)]
+    else:   # per-clip boxes x1,y1 ~ U{0..160}, w,h ~ U{32..160} clipped to 224, replicated over the 16 frames
+        bgen = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)
+        masks = []
+        for _ in range(B):
+            x1, y1 = np.random.randint(0, 161, 2)
+            w_, h_ = np.random.randint(32, 161, 2)
+            masks.append(bgen(np.tile(np.array([x1, y1, min(224, x1 + w_), min(224, y1 + h_)]), (16, 1))))
+    mask_u8.copy_(torch.from_numpy(np.stack(masks).astype(np.uint8)))
     mask_dev = mask_u8.clone()
     _Args.lr = 1.5e-4 * (B * world) / 256                          # run_mae_pretraining.py:217
     opt = optim_factory.create_optimizer(_Args, model)
@@ -166,9 +177,9 @@ def main():
     out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "ViT-B (enc 12x768, dec 4x384) 16x224x224 tube mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
+           "config": {"workload": "ViT-B (enc 12x768, dec 4x384) 16x224x224 " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
                                   "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
-                      "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "final_loss": round(last, 5),
+                      "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "final_loss": round(last, 5),
                       "step_mfma_frac": round(clips_per_s / world * STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}}
 
     if prof is not None:

@@ -88,6 +88,12 @@ int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, con
  * vis_idx [B,n_vis], msk_idx [B,N-n_vis]: ascending token ids per clip.  status[0] |= 1 if a clip's count differs. ---- */
 int mofo_mask_to_indices(const uint8_t* mask, int B, int N, int n_vis, int* vis_idx, int* msk_idx, int* status, void* stream);
 
+/* ---- on-device ingest (the step BEFORE the path): frames uint8 [B,H,W,T*3] = the reference's Stack()
+ * output (transforms.py:346-360) -> clips f32 [B,3,T,H,W] = ((u/255) - mean_c) / std_c, i.e. ToTorchFormatTensor(div=True)
+ * (transforms.py:363-382) + GroupNormalize (datasets.py:12-14) + the view/transpose at kinetics.py:492-493.  Bit-exact with
+ * the reference's fp32 arithmetic; cuts the H2D copy from 9.63 MB to 2.41 MB per clip. ---- */
+int mofo_ingest_u8(const uint8_t* frames, int B, int T, int H, int W, float* clips, void* stream);
+
 /* ---- tubelet gather for PatchEmbed over VISIBLE tokens only: modeling_finetune.py:238-248 + modeling_pretrain.py:90.
  * clips f32 [B,C,T,H,W]; token id = t*(H/p)*(W/p) + h*(W/p) + w; out bf16 [B*n_tok, C*pt*p*p], column order (c,pt,ph,pw)
  * = Conv3d weight order.  The GEMM (NT, POS_F32 epilogue) against proj.weight.view(D,-1) finishes PatchEmbed + pos. ---- */

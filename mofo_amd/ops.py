@@ -243,6 +243,16 @@ def attention_bwd(qkv, out, dout, lse2, B, N, H, scale, dqkv, delta):
     return dqkv
 
 
+def ingest_u8(frames, clips):
+    """frames uint8 [B,H,W,T*3] (reference Stack() layout) -> clips f32 [B,3,T,H,W], normalised as the reference does"""
+    _chk(frames, U8, "frames", 4), _chk(clips, F32, "clips", 5)
+    B, H, W, TC = frames.shape
+    if not frames.is_contiguous() or not clips.is_contiguous() or TC % 3 or clips.shape != (B, 3, TC // 3, H, W):
+        raise ValueError("ingest_u8: frames [B,H,W,T*3] contiguous, clips [B,3,T,H,W] contiguous")
+    _run("mofo_ingest_u8", ("ingest_u8",), 5.0 * frames.numel(), _p(frames), B, TC // 3, H, W, _p(clips))
+    return clips
+
+
 def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
     _chk(mask_u8, U8, "mask", 2), _chk(vis_idx, I32, "vis_idx", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(status, I32, "status")
     B, N = mask_u8.shape

@@ -208,6 +208,19 @@ def keyed_clips(n: int, cfg: OracleConfig, base_seed: int = 1000) -> torch.Tenso
         [np.random.RandomState(base_seed + i).standard_normal(shape).astype(np.float32) for i in range(n)]))
 
 
+def ingest_uint8(frames: torch.Tensor) -> torch.Tensor:
+    """uint8 [B,H,W,T*3] (Stack(), transforms.py:346-360) -> f32 [B,3,T,H,W]: ToTorchFormatTensor(div=True)
+    (transforms.py:363-382: permute to [T*3,H,W], .float().div(255.)), GroupNormalize (datasets.py:12-14: sub mean, div std
+    per channel, mean/std repeated per frame) and view(T,3,H,W).transpose(0,1) (kinetics.py:492-493)."""
+    B, H, W, TC = frames.shape
+    T = TC // 3
+    x = frames.permute(0, 3, 1, 2).contiguous().float().div(255.)                 # [B, T*3, H, W]
+    mean = torch.tensor(IMAGENET_MEAN * T, dtype=torch.float32)[None, :, None, None]
+    std = torch.tensor(IMAGENET_STD * T, dtype=torch.float32)[None, :, None, None]
+    x = x.sub(mean).div(std)
+    return x.view(B, T, 3, H, W).transpose(1, 2).contiguous()
+
+
 # --------------------------------------------------------------------------- forward pieces
 def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
     y = x @ w.t()

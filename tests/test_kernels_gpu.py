@@ -329,6 +329,17 @@ def test_mask_to_indices(dev):
     assert int(st.item()) == 0
 
 
+def test_ingest_uint8_bit_exact(dev):
+    """stacked uint8 frames -> normalised f32 clip, bit-exact with the reference's CPU transform arithmetic (oracle)"""
+    from mofo_amd import ops
+    from oracle import pretrain_oracle as O
+    for B, T, H, W in [(2, 16, 224, 224), (1, 32, 32, 48), (3, 16, 17, 33)]:
+        frames = torch.randint(0, 256, (B, H, W, T * 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(B))
+        clips = torch.empty(B, 3, T, H, W, dtype=F32, device=dev)
+        ops.ingest_u8(frames.to(dev), clips)
+        assert torch.equal(clips.cpu(), O.ingest_uint8(frames))
+
+
 @pytest.mark.parametrize("cfgname", ["TINY", "VIT_B"])
 def test_patch_gather_and_embed(dev, cfgname):
     from mofo_amd import ops

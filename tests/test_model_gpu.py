@@ -316,3 +316,28 @@ def test_gradient_sync_on_one_rank_rccl(dev):
     finally:
         dist.destroy_process_group()
         os.environ.pop("MOFO_FORCE_DP", None)
+
+
+def test_vit_large_32_frames_parity(dev):
+    """BASELINE config 4's architecture (ViT-L, 32x224x224 -> 3136 tokens, 320 visible) in bf16 against the oracle.
+    The reference hard-wires 16 frames; tables are extended with the same sincos formula."""
+    from mofo_amd import modeling_pretrain as mp
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=3, enc_heads=16, dec_dim=512, dec_depth=1, dec_heads=8)   # ViT-L widths, 3+1 blocks
+    model, P = _build(cfg, "xavier", dev)
+    x = O.keyed_clips(1, cfg)
+    np.random.seed(7)
+    mask = torch.from_numpy(O.tube_mask(cfg.grid, 0.9)[None]).bool()
+    assert int((~mask).sum()) == 320 and mask.shape[1] == 3136
+    loss = model.forward_loss(x.to(dev), mask.to(dev))
+    model.runtime().store.zero_grads()
+    loss.backward()
+    gn = float(model.runtime().grad_norm())
+    model.check_status()
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    ref_loss, ref_gn, grads = O.train_step(x, mask, P, cfg)
+    assert float(loss) == pytest.approx(ref_loss, rel=1e-3)
+    assert gn == pytest.approx(ref_gn, rel=2e-2)
+    g = {n: p.grad for n, p in model.named_parameters()}
+    for n in ("encoder.patch_embed.proj.weight", "encoder.blocks.0.attn.qkv.weight", "decoder.blocks.0.mlp.fc2.weight", "mask_token"):
+        assert _rel(g[n], grads[n]) < 6e-2, n

@@ -77,6 +77,15 @@ def test_cosine_schedule():
     assert np.array_equal(O.cosine_schedule(1.2e-3, 1e-5, 6, 11, warmup_epochs=2, warmup_steps=9), g["s3"])
 
 
+def test_ingest_uint8_matches_reference_transforms():
+    """fixture = the reference's Stack -> ToTorchFormatTensor(div=True) -> GroupNormalize -> view/transpose on PIL frames"""
+    g = _load("ingest.npz")
+    frames = torch.from_numpy(g["stacked"])[None]                # [1, H, W, T*3] uint8
+    got = O.ingest_uint8(frames)[0]
+    assert got.shape == g["clip"].shape
+    assert np.array_equal(got.numpy(), g["clip"])                # same fp32 operations: bit-exact
+
+
 # ----------------------------------------------------------------------------- tiny config, every tensor
 @pytest.mark.parametrize("mode", ["small", "xavier"])
 def test_tiny_full_parity(mode):

@@ -262,6 +262,27 @@ def main():
         np.savez_compressed(os.path.join(args.out, f"tiny_{mode}.npz"), **fx)
         print(f"tiny_{mode}: out_sum={out0.double().sum().item():.15f} out[0,0,:3]={out0[0,0,:3].tolist()} losses={losses} gn={norms}")
 
+    # ------------------------------------------------------------------ F7 ingest: Stack -> ToTorchFormatTensor -> GroupNormalize
+    # (transforms.py imports torchvision / albumentations at module level but these three classes use only numpy/torch/PIL)
+    for name in ("torchvision", "torchvision.transforms", "torchvision.transforms.functional", "albumentations"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            sys.modules[name] = m
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision.transforms"].functional = sys.modules["torchvision.transforms.functional"]
+    import transforms as ref_tf
+    from PIL import Image
+    rs = np.random.RandomState(77)
+    T, H, W = 16, 24, 40
+    frames = rs.randint(0, 256, size=(T, H, W, 3)).astype(np.uint8)
+    imgs = [Image.fromarray(frames[t], mode="RGB") for t in range(T)]
+    stacked, _ = ref_tf.Stack(roll=False)((imgs, None))                       # [H, W, T*3] uint8
+    ten, _ = ref_tf.ToTorchFormatTensor(div=True)((stacked, None))
+    ten, _ = ref_tf.GroupNormalize([0.485, 0.456, 0.406], [0.229, 0.224, 0.225])((ten, None))
+    clip = ten.view((T, 3) + ten.size()[-2:]).transpose(0, 1).contiguous()    # kinetics.py:492-493 -> [3, T, H, W]
+    np.savez_compressed(os.path.join(args.out, "ingest.npz"), stacked=np.ascontiguousarray(stacked), clip=clip.numpy())
+    print("ingest.npz", stacked.shape, clip.shape)
+
     if args.skip_vitb:
         return
 
