@@ -67,11 +67,13 @@ int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* str
 int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float eps, int M, int D,
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
-/* dx(f32) = dres (f32, may be NULL) + LN'(dy); dx_bf16 (may be NULL) = bf16 copy; dw/db accumulate (+=, atomics). */
+/* dx = dres + LN'(dy).  The incoming residual-stream gradient is dres (f32) OR dres_bf16 (bf16) OR neither; the result
+ * goes to dx (f32) and/or dx_bf16 (at least one).  dw/db accumulate (+=, atomics). */
 int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const float* x, int ldx, const float* w,
                        const float* mean, const float* rstd, const float* dres, int lddres, int M, int D,
                        int rows_in, int rows_out, int row_off,
-                       float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db, void* stream);
+                       float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db,
+                       const void* dres_bf16, int lddres_bf16, void* stream);
 
 /* ---- multi-head self-attention core: modeling_finetune.py:85-95 (q*scale, q@k^T, softmax, @v).
  * qkv is the fused projection output, bf16 [B*N, 3*H*64] (q | k | v, each head-major x 64); head_dim is 64 in every
@@ -104,8 +106,9 @@ int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int
  * x_full[b, n_vis + j] = mask_token + pos[msk_idx[b,j]]  (the visible half is the e2d GEMM's POS_F32 epilogue). ---- */
 int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx,
                           int B, int N, int n_vis, int D, float* x_full, void* stream);
-/* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows. */
-int mofo_assemble_bwd(const float* dx_full, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token, void* stream);
+/* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows.
+ * dx_full is f32 (dx_is_bf16 = 0) or bf16 (1). */
+int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token, void* stream);
 
 /* ---- reconstruction target + MSE: engine_for_pretraining.py:43-63 (un-normalise, patchify (p0 p1 p2) c,
  * per-(token,channel) standardise with UNBIASED var and 1e-6 after the sqrt, gather masked) and :27,67 (nn.MSELoss).

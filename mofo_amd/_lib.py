@@ -33,14 +33,14 @@ _SIGS = {
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp]),
+    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_ingest_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mofo_patch_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
-    "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mofo_target_mse": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp]),
     "mofo_sumsq": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "mofo_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp]),

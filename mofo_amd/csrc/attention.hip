@@ -99,8 +99,8 @@ __device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int&
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
 // and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
-template <int NW, int MODE, bool WHOLE, int OCC>
-__global__ __launch_bounds__(NW * 64, OCC) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
+template <int NW, int MODE, bool WHOLE>
+__global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
                                                           bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
@@ -253,8 +253,8 @@ __global__ __launch_bounds__(NW * 64, OCC) void attn_q_kernel(const bf16_t* __re
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int NW, bool WHOLE, int OCC>
-__global__ __launch_bounds__(NW * 64, OCC) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
+template <int NW, bool WHOLE>
+__global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int lddqkv) {
@@ -379,20 +379,11 @@ int pick_nw(int N) {
     if (forced == 4 || forced == 7) return forced;
     return 4;                     // 3 blocks/CU by waves; measured 3 % faster than 7-wave blocks even with a 6 % ragged tail
 }
-int pick_occ() {
-    static int v = -1;
-    if (v < 0) {
-        const char* e = getenv("MOFO_ATTN_OCC");
-        v = e ? atoi(e) : 0;
-    }
-    return v;
-}
-
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, 1); } else if (pick_occ() == 3) { LAUNCH_Q_(NW, MODE, false, 3); } else { LAUNCH_Q_(NW, MODE, false, 1); } } while (0)
-#define LAUNCH_Q_(NW, MODE, WH, OC)                                                                                     \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, OC>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
+#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true); } else { LAUNCH_Q_(NW, MODE, false); } } while (0)
+#define LAUNCH_Q_(NW, MODE, WH)                                                                                         \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
                        (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
 
@@ -439,9 +430,9 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
         default: LAUNCH_Q(4, 1); break;
     }
     MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
-#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, 1); } else if (pick_occ() == 3) { LAUNCH_KV_(NW, false, 3); } else { LAUNCH_KV_(NW, false, 1); } } while (0)
-#define LAUNCH_KV_(NW, WH, OC)                                                                                         \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, OC>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
+#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true); } else { LAUNCH_KV_(NW, false); } } while (0)
+#define LAUNCH_KV_(NW, WH)                                                                                             \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
     switch (nw) {

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       int lddres, int M, int D, int rows_in, int rows_out, int row_off,
                                                       float* __restrict__ dx, int lddx, bf16_t* __restrict__ dxb, int lddxb,
-                                                      float* __restrict__ dw, float* __restrict__ db) {
+                                                      float* __restrict__ dw, float* __restrict__ db,
+                                                      const bf16_t* __restrict__ dresb, int lddresb) {
     __shared__ float red[2][4][MAX_IT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 wv[NIT], aw[NIT], ab[NIT];
@@ -102,7 +103,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 if (c < D) {
                     xv[k][it] = *(const f32x4*)(x + xr[k] * ldx + c);
                     dv[k][it] = *(const u32x2*)(dy + (size_t)rr[k] * lddy + c);
-                    rv[k][it] = dres ? *(const f32x4*)(dres + xr[k] * lddres + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (dresb) {   // residual-stream gradient kept in bf16 (one tensor instead of an f32 + a bf16 copy)
+                        const u32x2 rb = *(const u32x2*)(dresb + xr[k] * lddresb + c);
+                        rv[k][it] = f32x4{bf16lo_to_f32(rb[0]), bf16hi_to_f32(rb[0]), bf16lo_to_f32(rb[1]), bf16hi_to_f32(rb[1])};
+                    } else {
+                        rv[k][it] = dres ? *(const f32x4*)(dres + xr[k] * lddres + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
                 } else {
                     xv[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
                     dv[k][it] = u32x2{0u, 0u};
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     f32x4 o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = rs[k] * (g[it][e] - c1 - xh[it][e] * c2) + rv[k][it][e];
-                    *(f32x4*)(dx + xr[k] * lddx + c) = o;
+                    if (dx) *(f32x4*)(dx + xr[k] * lddx + c) = o;
                     if (dxb) {
                         u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
                         *(u32x2*)(dxb + xr[k] * lddxb + c) = pk;
@@ -192,11 +198,14 @@ extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const
 
 extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
-                                  int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db, void* stream) {
-    if (!dy || !x || !w || !mean || !rstd || !dx || !dw || !db) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
+                                  int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
+                                  const void* dresb, int lddresb, void* stream) {
+    if (!dy || !x || !w || !mean || !rstd || !dw || !db) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
+    if (!dx && !dxb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: need dx (f32) and/or dx_bf16");
+    if (dres && dresb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: pass the residual gradient as f32 OR bf16, not both");
     int rc = ln_check("mofo_layernorm_bwd", M, D, rows_in, rows_out);
     if (rc) return rc;
-    if (lddy % 4 || ldx % 4 || lddx % 4 || (dres && lddres % 4) || (dxb && lddxb % 4))
+    if (lddy % 4 || ldx % 4 || (dx && lddx % 4) || (dres && lddres % 4) || (dxb && lddxb % 4) || (dresb && lddresb % 4))
         MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_bwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
@@ -206,7 +215,7 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(256);
-#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db)
+#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_bwd");

@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict_
 // 256 threads = CT column threads (one float4 each, CT = D/4 rounded up to a power-of-two divisor of 256) x RL row lanes;
 // a block covers RB rows; the masked rows' column sums are reduced over the row lanes in LDS, one atomic per column.
 constexpr int RB = 64;
-__global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restrict__ dx, int N, int n_vis, int D, int rows, int ct,
+template <bool BF16IN>
+__global__ __launch_bounds__(256) void assemble_bwd_kernel(const void* __restrict__ dxv, int N, int n_vis, int D, int rows, int ct,
                                                            bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {
     __shared__ f32x4 red[256];
     const int cthr = threadIdx.x % ct, rl = threadIdx.x / ct, nrl = 256 / ct;
@@ -104,10 +105,17 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const float* __restri
     if (c < D) {
         for (int r = r0 + rl; r < min(rows, r0 + RB); r += nrl) {
             const int b = r / N, j = r - b * N;
-            const f32x4 v = *(const f32x4*)(dx + (size_t)r * D + c);
+            f32x4 v;
+            u32x2 raw = {0u, 0u};
+            if constexpr (BF16IN) {
+                raw = *(const u32x2*)((const bf16_t*)dxv + (size_t)r * D + c);
+                v = f32x4{bf16lo_to_f32(raw[0]), bf16hi_to_f32(raw[0]), bf16lo_to_f32(raw[1]), bf16hi_to_f32(raw[1])};
+            } else {
+                v = *(const f32x4*)((const float*)dxv + (size_t)r * D + c);
+                raw = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+            }
             if (j < n_vis) {
-                u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
-                *(u32x2*)(d_e2d + ((size_t)b * n_vis + j) * D + c) = pk;
+                *(u32x2*)(d_e2d + ((size_t)b * n_vis + j) * D + c) = raw;
             } else {
                 acc += v;
             }
@@ -226,16 +234,20 @@ extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, 
     return MOFO_OK;
 }
 
-extern "C" int mofo_assemble_bwd(const float* dx_full, int B, int N, int n_vis, int D, void* d_e2d, float* d_mask_token,
-                                 void* stream) {
+extern "C" int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d,
+                                 float* d_mask_token, void* stream) {
     if (!dx_full || !d_e2d || !d_mask_token) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: null pointer");
     if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || D > 1024) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: bad sizes");
     const int rows = B * N;
     int ct = 1;
     while (ct * 4 < D) ct *= 2;     // column threads: power of two >= D/4
     if (ct > 256) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_assemble_bwd: D=%d too wide", D);
-    hipLaunchKernelGGL(assemble_bwd_kernel, dim3(ceil_div(rows, RB)), dim3(256), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
-                       rows, ct, (bf16_t*)d_e2d, d_mask_token);
+    if (dx_is_bf16)
+        hipLaunchKernelGGL(assemble_bwd_kernel<true>, dim3(ceil_div(rows, RB)), dim3(256), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
+                           rows, ct, (bf16_t*)d_e2d, d_mask_token);
+    else
+        hipLaunchKernelGGL(assemble_bwd_kernel<false>, dim3(ceil_div(rows, RB)), dim3(256), 0, (hipStream_t)stream, dx_full, N, n_vis, D,
+                           rows, ct, (bf16_t*)d_e2d, d_mask_token);
     MOFO_CHECK_LAUNCH("mofo_assemble_bwd");
     return MOFO_OK;
 }

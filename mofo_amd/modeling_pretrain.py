@@ -152,7 +152,7 @@ class _DecoderFn(torch.autograd.Function):
         w.dpred.copy_(g.reshape(w.Mm, -1))
         mod._rt.begin_backward()
         dx = mod._rt.decoder_backward(w, w.dpred, w.x_full, ctx.n_ret)
-        return dx.view(w.B, w.N, -1).clone(), None, None, None
+        return dx.view(w.B, w.N, -1).float(), None, None, None
 
 
 class _ModelFn(torch.autograd.Function):

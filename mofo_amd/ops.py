@@ -202,26 +202,41 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0):
-    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(dx, F32, "dx", 2), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
+    """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
+    (bf16) are the outputs, either may be None but not both."""
+    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
     D = x.shape[1]
     M = dy.shape[0] if M is None else M
     rows_in = M if rows_in is None else rows_in
     rows_out = rows_in if rows_out is None else rows_out
+    dres_f = dres_b = None
     if dres is not None:
-        _chk(dres, F32, "dres", 2)
+        if dres.dtype == BF16:
+            dres_b = _chk(dres, BF16, "dres", 2)
+        else:
+            dres_f = _chk(dres, F32, "dres", 2)
         if dres.shape != x.shape:
             raise ValueError("dres shape")
+    if dx is None and dxb is None:
+        raise ValueError("layernorm_bwd: need dx and/or dxb")
+    if dx is not None:
+        _chk(dx, F32, "dx", 2)
+        if dx.shape != x.shape:
+            raise ValueError("dx shape")
     if dxb is not None:
         _chk(dxb, BF16, "dxb", 2)
         if dxb.shape != x.shape:
             raise ValueError("dxb shape")
-    if dx.shape != x.shape or dy.shape[1] != D or dw.numel() != D or db.numel() != D or dy.shape[0] < M:
+    if dy.shape[1] != D or dw.numel() != D or db.numel() != D or dy.shape[0] < M:
         raise ValueError("layernorm_bwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_bwd: row map exceeds x")
-    _run("mofo_layernorm_bwd", ("ln_bwd",), (6.0 + (4.0 if dres is not None else 0.0) + 4.0 + (2.0 if dxb is not None else 0.0)) * M * D,
-         _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres), _ld(dres) if dres is not None else 0, M, D,
-         rows_in, rows_out, row_off, _p(dx), _ld(dx), _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db))
+    bytes_ = (6.0 + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
+              + (2.0 if dxb is not None else 0.0)) * M * D
+    _run("mofo_layernorm_bwd", ("ln_bwd",), bytes_,
+         _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
+         rows_in, rows_out, row_off, _p(dx), _ld(dx) if dx is not None else 0, _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
+         _p(dres_b), _ld(dres_b) if dres_b is not None else 0)
 
 
 def attention_fwd(qkv, B, N, H, scale, out, lse2):
@@ -283,11 +298,14 @@ def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
 
 
 def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
-    _chk(dx_full, F32, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2), _chk(d_mask_token, F32, "d_mask_token")
+    if dx_full is None or dx_full.dtype not in (F32, BF16):
+        raise TypeError("dx_full must be f32 or bf16")
+    _chk(dx_full, dx_full.dtype, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2), _chk(d_mask_token, F32, "d_mask_token")
     B, N, D = dx_full.shape
     if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or d_mask_token.numel() != D:
         raise ValueError("assemble_bwd: shape mismatch")
-    _run("mofo_assemble_bwd", ("assemble_bwd",), 4.0 * B * N * D, _p(dx_full), B, N, n_vis, D, _p(d_e2d), _p(d_mask_token))
+    isb = 1 if dx_full.dtype == BF16 else 0
+    _run("mofo_assemble_bwd", ("assemble_bwd",), (2.0 if isb else 4.0) * B * N * D, _p(dx_full), isb, B, N, n_vis, D, _p(d_e2d), _p(d_mask_token))
 
 
 def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, loss, dpred=None, target_out=None):

@@ -260,7 +260,9 @@ class PretrainRuntime:
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         # the weight-gradient GEMMs of a block run on a side stream while the next blocks' activation-gradient chain
         # proceeds, so everything they read (dh1, dx_mid copy, dqkv, dx_out copy) is double / triple buffered
-        return NS(dxA=e(M, D, dt=F32), dxB=e(M, D, dt=F32), ring=[e(M, D), e(M, D), e(M, D)], dxln=e(M, D),
+        # The residual-stream GRADIENT lives in bf16 only (ring / dxbB): each LayerNorm backward reads it as bf16 and writes
+        # one bf16 tensor -- no f32 copy is written and re-read (the forward residual stream stays f32).
+        return NS(ring=[e(M, D), e(M, D), e(M, D)], dxln=e(M, D),
                   sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(2)],
                   dao=e(M, D), delta=e(B * H * n, dt=F32),
                   ready=[torch.cuda.Event() for _ in range(2)] if self.dev.type == "cuda" else None,
@@ -351,10 +353,10 @@ class PretrainRuntime:
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
 
-    def _block_bwd(self, W, L, S, k, x_in, dx_out, dxb_out, dx_in, dxb_in, B, n, H):
-        """dx_out/dxb_out: gradient wrt the block output (fp32 + bf16 copy); writes dx_in/dxb_in.  dx_in may alias dx_out;
-        dxb_in must NOT alias dxb_out.  ``k`` = parity of the block: selects the scratch set whose buffers the block's
-        deferred weight-gradient launch (side stream) reads while the following block already runs."""
+    def _block_bwd(self, W, L, S, k, x_in, dxb_out, dxb_in, B, n, H):
+        """dxb_out: gradient wrt the block output (bf16); writes dxb_in, which must NOT alias dxb_out.  ``k`` = parity of
+        the block: selects the scratch set whose buffers the block's deferred weight-gradient launch (side stream) reads
+        while the following block already runs."""
         scale = 64 ** -0.5
         D = x_in.shape[1]
         T = S.sets[k]
@@ -364,12 +366,12 @@ class PretrainRuntime:
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, T.dh1, aux=L.h1)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dh1, W.fc1, S.dxln)
-        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dx_out, S.dxB, T.dxbB, W.g_ln2w, W.g_ln2b)
+        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
         ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
-        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, S.dxB, dx_in, dxb_in, W.g_ln1w, W.g_ln1b)
+        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
         ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
@@ -459,14 +461,14 @@ class PretrainRuntime:
         d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
         S.used = [False, False]
-        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, S.dxA, S.ring[0],
+        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
         cnt = 0
         j = 0
         for i in range(d.enc_depth - 1, -1, -1):
             x_in = w.enc[i - 1].x_out if i > 0 else w.enc_x0
-            self._block_bwd(self.encW[i], w.enc[i], S, j & 1, x_in, S.dxA, S.ring[j % 3], S.dxA, S.ring[(j + 1) % 3], w.B, w.n_vis, d.enc_heads)
+            self._block_bwd(self.encW[i], w.enc[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.n_vis, d.enc_heads)
             j += 1
             cnt += 1
             if cnt == 3 and i > 0:  # gradient buckets of three encoder blocks (~85 MB fp32 at ViT-B)
@@ -512,16 +514,16 @@ class PretrainRuntime:
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
         S.used = [False, False]
-        ops.host_op(lambda: (S.dxA.zero_(), S.ring[0].zero_()))
-        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, S.dxA, S.ring[0],
+        ops.host_op(lambda: S.ring[0].zero_())
+        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
                           s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         j = 0
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
-            self._block_bwd(self.decW[i], w.dec[i], S, j & 1, x_in, S.dxA, S.ring[j % 3], S.dxA, S.ring[(j + 1) % 3], w.B, w.N, d.dec_heads)
+            self._block_bwd(self.decW[i], w.dec[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.N, d.dec_heads)
             j += 1
         self._join_side(S)
-        return S.dxA
+        return S.ring[j % 3]       # gradient wrt the decoder input, bf16 [B*N, D]
 
     # ------------------------------------------------------------------ whole model
     def _forward(self, w: NS):

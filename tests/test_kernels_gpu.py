@@ -225,6 +225,12 @@ def test_layernorm_fwd_bwd(dev, M, D):
     dw.zero_(), db.zero_()
     ops.layernorm_bwd(dy, x, w, mean, rstd, None, dx, None, dw, db)
     assert _rel(dx, xr.grad) < 1e-5
+    # residual gradient given in bf16, bf16-only output (the form the training step uses)
+    dw.zero_(), db.zero_()
+    dres_b = dres.to(BF16)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dres_b, None, dxb, dw, db)
+    assert _rel(dxb, xr.grad + dres_b.float()) < 4e-3
+    assert _rel(dw, wr.grad) < 1e-4
 
 
 def test_layernorm_rowmap(dev):
@@ -383,6 +389,11 @@ def test_assemble_fwd_bwd(dev):
     ops.assemble_bwd(dx, nv, de, dt)
     assert torch.equal(de.view(Bc, nv, D), dx[:, :nv].to(BF16))
     assert _rel(dt, dx[:, nv:].sum((0, 1))) < 1e-5
+    dxh = dx.to(BF16)
+    dt.zero_()
+    ops.assemble_bwd(dxh, nv, de, dt)
+    assert torch.equal(de.view(Bc, nv, D), dxh[:, :nv])
+    assert _rel(dt, dxh[:, nv:].float().sum((0, 1))) < 1e-5
 
 
 @pytest.mark.parametrize("cfgname,normalize", [("TINY", True), ("VIT_B", True), ("VIT_B", False)])
