@@ -68,12 +68,15 @@ int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, 
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
 /* dx = dres + LN'(dy).  The incoming residual-stream gradient is dres (f32) OR dres_bf16 (bf16) OR neither; the result
- * goes to dx (f32) and/or dx_bf16 (at least one).  dw/db accumulate (+=, atomics). */
+ * goes to dx (f32) and/or dx_bf16 (at least one).  dw/db accumulate (+=): with partial_ws the per-block partials are stored
+ * and summed by a second tiny kernel (one writer per address, deterministic); without it every block adds atomically. */
 int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const float* x, int ldx, const float* w,
                        const float* mean, const float* rstd, const float* dres, int lddres, int M, int D,
                        int rows_in, int rows_out, int row_off,
                        float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db,
-                       const void* dres_bf16, int lddres_bf16, void* stream);
+                       const void* dres_bf16, int lddres_bf16,
+                       float* partial_ws /* >= 2*1024*D floats of scratch, or NULL: NULL falls back to contended atomics */,
+                       void* stream);
 
 /* ---- multi-head self-attention core: modeling_finetune.py:85-95 (q*scale, q@k^T, softmax, @v).
  * qkv is the fused projection output, bf16 [B*N, 3*H*64] (q | k | v, each head-major x 64); head_dim is 64 in every

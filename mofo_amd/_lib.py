@@ -33,7 +33,7 @@ _SIGS = {
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp]),
+    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_ingest_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
@@ -95,15 +95,20 @@ class EventProfiler:
         self.records.append((key, work, e0, e1))
 
     def summary(self):
+        """per class: launches, total ms, total work, max ms.  A launch that took more than 10x its class's 90th percentile
+        (a one-off stall inside the bracket; classes are multi-modal, e.g. encoder vs decoder shapes, hence not the median)
+        is left out and counted in 'dropped'."""
         torch.cuda.synchronize()
-        out = {}
+        per = {}
         for key, work, e0, e1 in self.records:
-            d = out.setdefault(key, {"launches": 0, "ms": 0.0, "work": 0.0, "max_ms": 0.0})
-            t = e0.elapsed_time(e1)
-            d["launches"] += 1
-            d["ms"] += t
-            d["work"] += work
-            d["max_ms"] = max(d["max_ms"], t)
+            per.setdefault(key, []).append((e0.elapsed_time(e1), work))
+        out = {}
+        for key, lst in per.items():
+            ts = sorted(t for t, _ in lst)
+            p90 = ts[min(len(ts) - 1, (9 * len(ts)) // 10)]
+            keep = [(t, w) for t, w in lst if t <= 10.0 * p90 or len(lst) < 20]
+            out[key] = {"launches": len(keep), "ms": sum(t for t, _ in keep), "work": sum(w for _, w in keep),
+                        "max_ms": max(t for t, _ in keep), "dropped": len(lst) - len(keep)}
         return out
 
 

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       int lddres, int M, int D, int rows_in, int rows_out, int row_off,
                                                       float* __restrict__ dx, int lddx, bf16_t* __restrict__ dxb, int lddxb,
                                                       float* __restrict__ dw, float* __restrict__ db,
-                                                      const bf16_t* __restrict__ dresb, int lddresb) {
+                                                      const bf16_t* __restrict__ dresb, int lddresb, float* __restrict__ partial) {
     __shared__ float red[2][4][MAX_IT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 wv[NIT], aw[NIT], ab[NIT];
@@ -116,33 +116,46 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                 }
             }
         }
+        // both rows' statistics are reduced TOGETHER: four independent values per shuffle step instead of four dependent
+        // 6-step chains (the cross-lane shuffles go through the LDS crossbar; their latency, not HBM, bounded this kernel)
+        f32x4 xh[2][NIT], g[2][NIT];
+        float c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+        const float live1 = has2 ? 1.0f : 0.0f;   // the duplicated row of an odd tail must not count in dw / db
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
-            if (k == 1 && !has2) break;
-            f32x4 xh[NIT], g[NIT];
-            float c1 = 0.f, c2 = 0.f;
+            const float live = k == 0 ? 1.0f : live1;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const float d[4] = {bf16lo_to_f32(dv[k][it][0]), bf16hi_to_f32(dv[k][it][0]), bf16lo_to_f32(dv[k][it][1]), bf16hi_to_f32(dv[k][it][1])};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    xh[it][e] = (xv[k][it][e] - mu[k]) * rs[k];
-                    g[it][e] = d[e] * wv[it][e];
-                    c1 += g[it][e];
-                    c2 += g[it][e] * xh[it][e];
-                    aw[it][e] += d[e] * xh[it][e];
-                    ab[it][e] += d[e];
+                    xh[k][it][e] = (xv[k][it][e] - mu[k]) * rs[k];
+                    g[k][it][e] = d[e] * wv[it][e];
+                    c1[k] += g[k][it][e];
+                    c2[k] += g[k][it][e] * xh[k][it][e];
+                    aw[it][e] += live * d[e] * xh[k][it][e];
+                    ab[it][e] += live * d[e];
                 }
             }
-            c1 = wave_sum(c1) / D;
-            c2 = wave_sum(c2) / D;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float t0 = __shfl_xor(c1[0], o, 64), t1 = __shfl_xor(c2[0], o, 64);
+            const float t2 = __shfl_xor(c1[1], o, 64), t3 = __shfl_xor(c2[1], o, 64);
+            c1[0] += t0; c2[0] += t1; c1[1] += t2; c2[1] += t3;
+        }
+        const float invD = 1.0f / D;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (k == 1 && !has2) break;
+            const float m1 = c1[k] * invD, m2 = c2[k] * invD;
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = (it * 64 + lane) * 4;
                 if (c < D) {
                     f32x4 o;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = rs[k] * (g[it][e] - c1 - xh[it][e] * c2) + rv[k][it][e];
+                    for (int e = 0; e < 4; ++e) o[e] = rs[k] * (g[k][it][e] - m1 - xh[k][it][e] * m2) + rv[k][it][e];
                     if (dx) *(f32x4*)(dx + xr[k] * lddx + c) = o;
                     if (dxb) {
                         u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
@@ -165,9 +178,34 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
     for (int c = threadIdx.x; c < D; c += 256) {
         const float sw = red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c];
         const float sb = red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c];
-        atomicAdd(dw + c, sw);
-        atomicAdd(db + c, sb);
+        if (partial) {   // every block adding into the SAME D addresses runs at ~1/14 of the atomic rate: store, reduce later
+            partial[((size_t)blockIdx.x * 2) * D + c] = sw;
+            partial[((size_t)blockIdx.x * 2 + 1) * D + c] = sb;
+        } else {
+            atomicAdd(dw + c, sw);
+            atomicAdd(db + c, sb);
+        }
     }
+}
+
+// dw[c] += sum_b partial[b][0][c], db[c] += sum_b partial[b][1][c].  grid (D/64, 2, FIN_SLICES): each block sums a slice of
+// the block range (4 row lanes x 64 columns, coalesced 256-B rows) and adds it atomically: FIN_SLICES adders per address
+// instead of up to 1024.
+constexpr int FIN_SLICES = 16;
+__global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __restrict__ partial, int nblocks, int D,
+                                                               float* __restrict__ dw, float* __restrict__ db) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int which = blockIdx.y;                                  // 0: dw, 1: db
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (nblocks + FIN_SLICES - 1) / FIN_SLICES;
+    const int b0 = blockIdx.z * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (c < D)
+        for (int b = b0 + part; b < b1; b += 4) s += partial[((size_t)b * 2 + which) * D + c];
+    red[part][cl] = s;
+    __syncthreads();
+    if (part == 0 && c < D && b0 < b1) atomicAdd((which ? db : dw) + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
 }  // namespace
@@ -199,7 +237,7 @@ extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const
 extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
                                   int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
-                                  const void* dresb, int lddresb, void* stream) {
+                                  const void* dresb, int lddresb, float* partial_ws, void* stream) {
     if (!dy || !x || !w || !mean || !rstd || !dw || !db) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
     if (!dx && !dxb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: need dx (f32) and/or dx_bf16");
     if (dres && dresb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: pass the residual gradient as f32 OR bf16, not both");
@@ -215,9 +253,13 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
     if (blocks > 1024) blocks = 1024;
     if (blocks < 1) blocks = 1;
     dim3 grid(blocks), block(256);
-#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb)
+#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_bwd");
+    if (partial_ws) {
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(ceil_div(D, 64), 2, FIN_SLICES), dim3(256), 0, s, (const float*)partial_ws, blocks, D, dw, db);
+        MOFO_CHECK_LAUNCH("mofo_layernorm_bwd(finalize)");
+    }
     return MOFO_OK;
 }

@@ -201,7 +201,7 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
     return y
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0):
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):
     """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
     (bf16) are the outputs, either may be None but not both."""
     _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
@@ -231,12 +231,16 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         raise ValueError("layernorm_bwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_bwd: row map exceeds x")
+    if partial_ws is not None:
+        _chk(partial_ws, F32, "partial_ws", 1)
+        if partial_ws.numel() < 2 * 1024 * D:
+            raise ValueError("partial_ws must hold 2*1024*D floats")
     bytes_ = (6.0 + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
               + (2.0 if dxb is not None else 0.0)) * M * D
     _run("mofo_layernorm_bwd", ("ln_bwd",), bytes_,
          _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
          rows_in, rows_out, row_off, _p(dx), _ld(dx) if dx is not None else 0, _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
-         _p(dres_b), _ld(dres_b) if dres_b is not None else 0)
+         _p(dres_b), _ld(dres_b) if dres_b is not None else 0, _p(partial_ws))
 
 
 def attention_fwd(qkv, B, N, H, scale, out, lse2):

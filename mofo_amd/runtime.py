@@ -228,6 +228,8 @@ class PretrainRuntime:
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
+        dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)
+        self.ln_ws = torch.empty(2 * 1024 * dmax, dtype=F32, device=self.dev)   # LN-backward dgamma/dbeta block partials
         self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
 
     # ------------------------------------------------------------------ weights
@@ -366,12 +368,12 @@ class PretrainRuntime:
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, T.dh1, aux=L.h1)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dh1, W.fc1, S.dxln)
-        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b)
+        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b, partial_ws=self.ln_ws)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
         ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
-        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
+        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b, partial_ws=self.ln_ws)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
         ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
@@ -462,7 +464,7 @@ class PretrainRuntime:
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
         S.used = [False, False]
         ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
-                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
+                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), partial_ws=self.ln_ws)
         seg = 1 if self.dec_prefix is not None else 0
         cnt = 0
         j = 0
@@ -516,7 +518,8 @@ class PretrainRuntime:
         S.used = [False, False]
         ops.host_op(lambda: S.ring[0].zero_())
         ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
-                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret,
+                          partial_ws=self.ln_ws)
         j = 0
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)

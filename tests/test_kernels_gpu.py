@@ -225,12 +225,14 @@ def test_layernorm_fwd_bwd(dev, M, D):
     dw.zero_(), db.zero_()
     ops.layernorm_bwd(dy, x, w, mean, rstd, None, dx, None, dw, db)
     assert _rel(dx, xr.grad) < 1e-5
-    # residual gradient given in bf16, bf16-only output (the form the training step uses)
-    dw.zero_(), db.zero_()
+    # residual gradient given in bf16, bf16-only output, block partials through a workspace (the form the step uses);
+    # dw/db ACCUMULATE: pre-fill to check the += semantics
+    dw.fill_(0.25), db.fill_(-0.5)
     dres_b = dres.to(BF16)
-    ops.layernorm_bwd(dy, x, w, mean, rstd, dres_b, None, dxb, dw, db)
+    ws = torch.empty(2 * 1024 * D, dtype=F32, device=dev)
+    ops.layernorm_bwd(dy, x, w, mean, rstd, dres_b, None, dxb, dw, db, partial_ws=ws)
     assert _rel(dxb, xr.grad + dres_b.float()) < 4e-3
-    assert _rel(dw, wr.grad) < 1e-4
+    assert _rel(dw - 0.25, wr.grad) < 1e-4 and _rel(db + 0.5, br.grad) < 1e-4
 
 
 def test_layernorm_rowmap(dev):
