@@ -93,7 +93,9 @@ __global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict_
 
 // 256 threads = CT column threads (one float4 each, CT = D/4 rounded up to a power-of-two divisor of 256) x RL row lanes;
 // a block covers RB rows; the masked rows' column sums are reduced over the row lanes in LDS, one atomic per column.
-constexpr int RB = 64;
+// RB rows per block: few blocks => few adders on the same D addresses of d_mask_token (contended same-address f32 atomics
+// run ~14x below the atomic rate); 256 rows x D x 2 B per block still leaves ~800 blocks at ViT-B, B=32.
+constexpr int RB = 256;
 template <bool BF16IN>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const void* __restrict__ dxv, int N, int n_vis, int D, int rows, int ct,
                                                            bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {
