@@ -88,6 +88,15 @@ int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, con
                        const float* lse2, int B, int N, int H, float scale,
                        void* dqkv, int lddqkv, float* delta, void* stream);
 
+/* the three parts of mofo_attention_bwd as separate entries, so that a caller can run the dQ pass and the dK/dV pass
+ * (independent once delta is known; each alone keeps the MFMA pipe ~35 % busy) concurrently on two streams:
+ *   delta[b,h,q] = sum_d dout[q,h,d] * out[q,h,d];  dq -> first third of dqkv;  dk, dv -> second and third thirds. */
+int mofo_attention_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* stream);
+int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                          int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
+int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                           int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
+
 /* ---- masks -> index lists: replaces the boolean gathers x[~mask] / pos[mask] of modeling_pretrain.py:90,261-262
  * and engine_for_pretraining.py:63 (which cost a device->host sync in the reference).  mask: uint8 [B,N], 1 = masked.
  * vis_idx [B,n_vis], msk_idx [B,N-n_vis]: ascending token ids per clip.  status[0] |= 1 if a clip's count differs. ---- */

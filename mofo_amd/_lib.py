@@ -37,6 +37,9 @@ _SIGS = {
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_ingest_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "mofo_attention_delta": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mofo_attention_bwd_dq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
+    "mofo_attention_bwd_dkv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mofo_patch_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -127,18 +127,10 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     float L2 = 0.f, dl = 0.f;
     if constexpr (MODE == 1) {
         const bf16_t* dop = dout + ((size_t)b * N + qrow) * lddo + h * HD;
-        const bf16_t* op = out + ((size_t)b * N + qrow) * ldo + h * HD;
-        float part = 0.f;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            dof[ks] = *(const bf16x8*)(dop + 16 * ks + 8 * hh);
-            const bf16x8 ov = *(const bf16x8*)(op + 16 * ks + 8 * hh);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) part += (float)dof[ks][j] * (float)ov[j];
-        }
-        dl = part + __shfl_xor(part, 32, 64);
+        for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(dop + 16 * ks + 8 * hh);
         L2 = lse2[((size_t)b * H + h) * N + qrow];
-        if (qvalid && hh == 0) delta[((size_t)b * H + h) * N + qi] = dl;
+        dl = delta[((size_t)b * H + h) * N + qrow];     // rowsum(dO * O), from attn_delta_kernel
     }
 
     f32x16 o0 = zero16(), o1 = zero16();
@@ -368,6 +360,33 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
 }
 
+// delta[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]: 8 lanes per (token, head), 16-B loads, 3-step shuffle reduce.
+// Its own kernel so that the dQ pass and the dK/dV pass (which both need it) can run concurrently on two streams.
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ dout,
+                                                         int lddo, int N, int H, long long pairs, float* __restrict__ delta) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pr = i >> 3;
+    const int ch = (int)(i & 7);
+    float part = 0.f;
+    if (pr < pairs) {
+        const long long tok = pr / H;
+        const int h = (int)(pr - tok * H);
+        const bf16x8 a = *(const bf16x8*)(dout + tok * lddo + h * HD + ch * 8);
+        const bf16x8 o = *(const bf16x8*)(out + tok * ldo + h * HD + ch * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += (float)a[j] * (float)o[j];
+    }
+    part += __shfl_xor(part, 1, 64);
+    part += __shfl_xor(part, 2, 64);
+    part += __shfl_xor(part, 4, 64);
+    if (pr < pairs && ch == 0) {
+        const long long tok = pr / H;
+        const int h = (int)(pr - tok * H);
+        const long long b = tok / N, q = tok - b * N;
+        delta[((size_t)b * H + h) * N + q] = part;
+    }
+}
+
 int pick_nw(int N) {
     static int forced = -1;
     if (forced < 0) {
@@ -413,33 +432,69 @@ extern "C" int mofo_attention_fwd(const void* qkv, int ldqkv, int B, int N, int 
     return MOFO_OK;
 }
 
-extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
-                                  const float* lse2_in, int B, int N, int H, float scale, void* dqkv, int lddqkv,
-                                  float* delta, void* stream) {
-    int rc = check_common("mofo_attention_bwd", qkv, ldqkv, B, N, H);
+static int bwd_check(const char* who, const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                     int B, int N, int H, void* dqkv, int lddqkv) {
+    int rc = check_common(who, qkv, ldqkv, B, N, H);
     if (rc) return rc;
-    if (!out || !dout || !lse2_in || !dqkv || !delta) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_bwd: null pointer");
-    if (ldo % 8 || lddo % 8 || lddqkv % 4 || lddqkv < 3 * H * 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_bwd: bad leading dims");
+    if (!dout || !lse2 || !dqkv || !delta) MOFO_FAIL(MOFO_EINVAL, "%s: null pointer", who);
+    if (lddo % 8 || lddqkv % 4 || lddqkv < 3 * H * 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: bad leading dims", who);
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* stream) {
+    if (!out || !dout || !delta) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: null pointer");
+    if (B <= 0 || N <= 0 || H <= 0 || ldo % 8 || lddo % 8) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: bad sizes");
+    const long long pairs = (long long)B * N * H;
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out, ldo,
+                       (const bf16_t*)dout, lddo, N, H, pairs, delta);
+    MOFO_CHECK_LAUNCH("mofo_attention_delta");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2_in, const float* delta_in,
+                                     int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream) {
+    int rc = bwd_check("mofo_attention_bwd_dq", qkv, ldqkv, dout, lddo, lse2_in, delta_in, B, N, H, dqkv, lddqkv);
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
     float* lse2 = const_cast<float*>(lse2_in);
-    const int nw = pick_nw(N);
-    switch (nw) {
+    float* delta = const_cast<float*>(delta_in);
+    void* out = nullptr; int ldo = 0;
+    switch (pick_nw(N)) {
         case 7: LAUNCH_Q(7, 1); break;
         case 5: LAUNCH_Q(5, 1); break;
         default: LAUNCH_Q(4, 1); break;
     }
-    MOFO_CHECK_LAUNCH("mofo_attention_bwd(dq)");
+    MOFO_CHECK_LAUNCH("mofo_attention_bwd_dq");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                                      int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream) {
+    int rc = bwd_check("mofo_attention_bwd_dkv", qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, dqkv, lddqkv);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const float c = scale * 1.4426950408889634f;
 #define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true); } else { LAUNCH_KV_(NW, false); } } while (0)
 #define LAUNCH_KV_(NW, WH)                                                                                             \
     hipLaunchKernelGGL((attn_dkv_kernel<NW, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
-    switch (nw) {
+    switch (pick_nw(N)) {
         case 7: LAUNCH_KV(7); break;
         case 5: LAUNCH_KV(5); break;
         default: LAUNCH_KV(4); break;
     }
-    MOFO_CHECK_LAUNCH("mofo_attention_bwd(dkdv)");
+    MOFO_CHECK_LAUNCH("mofo_attention_bwd_dkv");
     return MOFO_OK;
+}
+
+extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
+                                  const float* lse2, int B, int N, int H, float scale, void* dqkv, int lddqkv,
+                                  float* delta, void* stream) {
+    int rc = mofo_attention_delta(out, ldo, dout, lddo, B, N, H, delta, stream);
+    if (rc) return rc;
+    rc = mofo_attention_bwd_dq(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);
+    if (rc) return rc;
+    return mofo_attention_bwd_dkv(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);
 }

@@ -272,6 +272,36 @@ def ingest_u8(frames, clips):
     return clips
 
 
+def _attn_bwd_chk(qkv, out, dout, lse2, B, N, H, dqkv, delta):
+    _chk(qkv, BF16, "qkv", 2), _chk(dout, BF16, "dout", 2), _chk(dqkv, BF16, "dqkv", 2), _chk(lse2, F32, "lse2"), _chk(delta, F32, "delta")
+    if out is not None:
+        _chk(out, BF16, "out", 2)
+        if out.shape != (B * N, H * 64):
+            raise ValueError("out shape")
+    if (qkv.shape != (B * N, 3 * H * 64) or dqkv.shape != qkv.shape or dout.shape != (B * N, H * 64)
+            or lse2.numel() != B * H * N or delta.numel() != B * H * N):
+        raise ValueError("attention backward: shape mismatch")
+
+
+def attention_delta(out, dout, B, N, H, delta):
+    _chk(out, BF16, "out", 2), _chk(dout, BF16, "dout", 2), _chk(delta, F32, "delta")
+    if out.shape != (B * N, H * 64) or dout.shape != out.shape or delta.numel() != B * H * N:
+        raise ValueError("attention_delta: shape mismatch")
+    _run("mofo_attention_delta", ("attn_delta",), 4.0 * out.numel(), _p(out), _ld(out), _p(dout), _ld(dout), B, N, H, _p(delta))
+
+
+def attention_bwd_dq(qkv, dout, lse2, delta, B, N, H, scale, dqkv):
+    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta)
+    _run("mofo_attention_bwd_dq", ("attn_bwd_dq",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
+         B, N, H, scale, _p(dqkv), _ld(dqkv))
+
+
+def attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv):
+    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta)
+    _run("mofo_attention_bwd_dkv", ("attn_bwd_dkv",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
+         B, N, H, scale, _p(dqkv), _ld(dqkv))
+
+
 def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
     _chk(mask_u8, U8, "mask", 2), _chk(vis_idx, I32, "vis_idx", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(status, I32, "status")
     B, N = mask_u8.shape

@@ -86,21 +86,58 @@ class FusedAdamW(torch.optim.Optimizer):
                   max_norm=float(max_norm) if max_norm else 0.0)
         st.mark_shadow_fresh()
 
-    # checkpoint: flat moments + step (the model's state_dict carries the parameters under the reference's names)
+    # checkpoint.  Written in torch.optim.AdamW's own state_dict layout -- state[i] = {'step','exp_avg','exp_avg_sq'} with i
+    # counting parameters group by group, param_groups[g]['params'] = index lists -- i.e. exactly what the reference's
+    # utils.save_model (utils.py:417-423) stores under 'optimizer', so checkpoints interchange in both directions.
+    def _indexed_params(self):
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        out, i = [], 0
+        for g in self.param_groups:
+            for p in g["params"]:
+                out.append((i, names[id(p)], p))
+                i += 1
+        return out
+
     def state_dict(self):
-        return {"state": {"step": self._step, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq, "format": "mofo_amd.flat.v1"},
-                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+        _, st = self._bind()
+        state = {}
+        for i, name, p in self._indexed_params():
+            o, n = st.offset[name], p.numel()
+            state[i] = {"step": torch.tensor(float(self._step)), "exp_avg": self.exp_avg[o:o + n].view(p.shape).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[o:o + n].view(p.shape).clone()}
+        groups, i = [], 0
+        for g in self.param_groups:
+            d = {k: v for k, v in g.items() if k != "params"}
+            d["params"] = list(range(i, i + len(g["params"])))
+            i += len(g["params"])
+            groups.append(d)
+        return {"state": state if self._step > 0 else {}, "param_groups": groups}
 
     def load_state_dict(self, sd):
-        self._bind()
-        s = sd["state"]
-        if s.get("format") != "mofo_amd.flat.v1" or s["exp_avg"].numel() != self.exp_avg.numel():
-            raise ValueError("optimizer state is not a mofo_amd flat AdamW state for this model")
-        self._step = int(s["step"])
-        self.exp_avg.copy_(s["exp_avg"])
-        self.exp_avg_sq.copy_(s["exp_avg_sq"])
+        _, st = self._bind()
+        idx = self._indexed_params()
+        if len(sd["param_groups"]) != len(self.param_groups) or sum(len(g["params"]) for g in sd["param_groups"]) != len(idx):
+            raise ValueError("optimizer state does not match this model's parameter groups")
+        state = sd["state"]
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = set()
+        for i, name, p in idx:
+            if i not in state:
+                continue
+            e = state[i]
+            o, n = st.offset[name], p.numel()
+            if tuple(e["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state shape mismatch for {name}")
+            self.exp_avg[o:o + n].copy_(e["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(e["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(e["step"])))
+        if len(steps) > 1:
+            raise ValueError("parameters carry different step counts; the fused update keeps one")
+        self._step = steps.pop() if steps else 0
         for g, saved in zip(self.param_groups, sd["param_groups"]):
             g.update({k: v for k, v in saved.items() if k != "params"})
+            g.setdefault("_decayed", g.get("weight_decay", 0) > 0)
 
 
 def create_optimizer(args, model, get_num_layer=None, get_layer_scale=None, filter_bias_and_bn=True, skip_list=None):

@@ -294,6 +294,37 @@ def test_attention_fwd_bwd(dev, B, N, H):
         assert _rel(dqkv[:, sl], g[:, sl]) < 2e-2, name
 
 
+def test_attention_bwd_split_entries(dev):
+    """delta / dQ / dK,dV as separate C-ABI calls (what the runtime issues on two streams) == the combined call"""
+    from mofo_amd import ops
+    B, N, H = 2, 224, 3
+    D = H * 64
+    qkv = _rand((B * N, 3 * D), dev, 1, 1.2)
+    out = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, 0.125, out, lse2)
+    dout = _rand((B * N, D), dev, 2)
+    ref = torch.empty_like(qkv)
+    delta = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_bwd(qkv, out, dout, lse2, B, N, H, 0.125, ref, delta)
+    got = torch.zeros_like(qkv)
+    d2 = torch.empty_like(delta)
+    ops.attention_delta(out, dout, B, N, H, d2)
+    assert torch.equal(d2, delta)
+    want = (dout.float() * out.float()).view(B, N, H, 64).sum(-1).permute(0, 2, 1).reshape(-1)
+    assert torch.allclose(d2, want, rtol=1e-4, atol=1e-4)
+    side = torch.cuda.Stream()
+    ev = torch.cuda.Event()
+    ev.record()
+    side.wait_event(ev)
+    ops.use_stream(side)
+    ops.attention_bwd_dkv(qkv, dout, lse2, d2, B, N, H, 0.125, got)
+    ops.use_stream(None)
+    ops.attention_bwd_dq(qkv, dout, lse2, d2, B, N, H, 0.125, got)
+    torch.cuda.synchronize()
+    assert torch.equal(got, ref)
+
+
 def test_attention_spiky_softmax(dev):
     """one key dominates late in the sequence -> the online-softmax rescale branch must fire and be right."""
     from mofo_amd import ops

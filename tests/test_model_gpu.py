@@ -274,6 +274,19 @@ def test_bb_engine_and_checkpoint_roundtrip(dev, tmp_path):
     for (n1, p1), (n2, p2) in zip(model.state_dict().items(), model2.state_dict().items()):
         assert n1 == n2 and torch.equal(p1, p2)
     assert opt2._step == opt._step and torch.equal(opt2.exp_avg, opt.exp_avg) and torch.equal(opt2.exp_avg_sq, opt.exp_avg_sq)
+    # the optimizer entry has torch.optim.AdamW's layout: a stock AdamW over the same parameters loads it, and its
+    # state_dict loads back (what the reference's utils.save_model / auto_load_model exchange)
+    osd = ck["optimizer"]
+    assert set(osd) == {"state", "param_groups"} and set(osd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+    torch_groups = [{"params": g["params"], "weight_decay": g["weight_decay"]} for g in opt.param_groups]
+    topt = torch.optim.AdamW(torch_groups, lr=1.5e-4, betas=(0.9, 0.95), eps=1e-8)
+    topt.load_state_dict({"state": osd["state"], "param_groups": [{**tg, "params": sg["params"]} for tg, sg in
+                                                                  zip(topt.state_dict()["param_groups"], osd["param_groups"])]})
+    p0 = opt.param_groups[0]["params"][0]
+    assert torch.equal(topt.state[p0]["exp_avg"].to(dev), osd["state"][0]["exp_avg"].to(dev))
+    opt3 = optim_factory.create_optimizer(_Args, model2)
+    opt3.load_state_dict(topt.state_dict())
+    assert opt3._step == opt._step and torch.equal(opt3.exp_avg, opt.exp_avg)
     # the two replicas continue identically
     xm, mm = x.to(dev), masks.bool().to(dev)
     l1 = model.forward_loss(xm, mm)
