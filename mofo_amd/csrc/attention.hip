@@ -12,6 +12,7 @@
 #include "common.h"
 #include "../../include/mofo_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -52,9 +53,9 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* tile, int s2, int
     const unsigned char* a1 = tile + r1 * RS + ((chunk ^ swz(r1)) << 4) + sub;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
-    s16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    // compose as 32-bit words (element-wise 16-bit assembly made hipcc emit v_perm / v_or / v_mov chains)
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
     return __builtin_bit_cast(bf16x8, r);
 }
 
@@ -167,18 +168,20 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         if (nkt > 1) gload(1);
     }
 
-    for (int kt = 0; kt < nkt; ++kt) {
+    // the tile body is instantiated twice: full tiles carry NO masking code; only a ragged last tile pays for the
+    // per-element key-index compare / select (the single-version loop spent ~64 VALU per tile on it)
+    auto tile = [&](int kt, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const unsigned char* Kt = smem + (WHOLE ? kt : (kt & 1)) * 2 * TILE;
         const unsigned char* Vt = Kt + TILE;
         f32x16 s = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, ks, lane), qf[ks], s, 0, 0, 0);
-        const bool tail = (kt * 32 + 32 > N);
         float p[16];
         if constexpr (MODE == 0) {
             // running max m is kept in RAW score units; p = exp2(c * s - c * m) is one FMA + one v_exp per element
             float mx = NEG_BIG;
-            if (tail) {
+            if constexpr (MASKED) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kt * 32 + acc_row(r, hh) >= N) s[r] = NEG_BIG;
@@ -216,8 +219,10 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, ks, lane), dof[ks], dp, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pr = fast_exp2(s[r] * c - L2);
-                if (tail && (kt * 32 + acc_row(r, hh) >= N)) pr = 0.f;
+                float pr = fast_exp2(fmaf(s[r], c, -L2));
+                if constexpr (MASKED) {
+                    if (kt * 32 + acc_row(r, hh) >= N) pr = 0.f;
+                }
                 p[r] = pr * (dp[r] - dl);
             }
             const bf16x8 f0 = pack_frag(p, 0), f1 = pack_frag(p, 1);
@@ -231,7 +236,10 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             __syncthreads();
             if (kt + 2 < nkt) gload(kt + 2);
         }
-    }
+    };
+    const int nfull = N >> 5;
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+    if (nfull < nkt) tile(nfull, std::true_type{});
 
     if (!qvalid) return;
     if constexpr (MODE == 0) {

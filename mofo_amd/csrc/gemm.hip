@@ -100,9 +100,9 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
         const unsigned char* a1 = lds_tile + kr1 * 256 + ((unit ^ col_key(kr1)) << 5) + 8 * pp;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
-        s16x8 r;
-        r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-        r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+        // compose as 32-bit words (element-wise 16-bit assembly made hipcc emit v_perm / v_or / v_mov chains)
+        const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+        const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
         return __builtin_bit_cast(bf16x8, r);
     }
 }
