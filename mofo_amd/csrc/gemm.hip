@@ -25,10 +25,11 @@
 #include "common.h"
 #include "../../include/mofo_hip.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 constexpr int OPL_ROW = 0, OPL_COL = 1;
 
@@ -53,6 +54,26 @@ struct GroupP {
     int start[MAXG + 1];   // first block of each problem; start[count] = grid size
     int count;
 };
+
+// Debug build only (-DMOFO_GEMM_TRACE, tools/gemm_trace.py): per-block phase timestamps (s_memtime) + the CU the block ran on.
+#ifndef MOFO_GEMM_PRIO
+#define MOFO_GEMM_PRIO 0
+#endif
+#ifdef MOFO_GEMM_TRACE
+__device__ unsigned long long g_trace[1 << 19];
+#define MOFO_TRACE(slot)                                                                          \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < (1 << 16)) g_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#define MOFO_TRACE_ID()                                                                           \
+    do {                                                                                          \
+        if (threadIdx.x == 0 && blockIdx.x < (1 << 16))                                           \
+            g_trace[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | __builtin_amdgcn_s_getreg(63492); \
+    } while (0)
+#else
+#define MOFO_TRACE(slot)
+#define MOFO_TRACE_ID()
+#endif
 
 __device__ __forceinline__ int col_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
@@ -122,6 +143,22 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     __shared__ __attribute__((aligned(16))) unsigned char smem[(VAR == 0 ? 2 : 1) * STG];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    MOFO_TRACE(0);
+    MOFO_TRACE_ID();
+#ifdef MOFO_GEMM_STAGGER
+    if (blockIdx.x >= 256 && blockIdx.x < 768) {   // experiment: one-time phase offset of the 2nd/3rd resident block of every CU
+        const int n = (blockIdx.x >> 8) * MOFO_GEMM_STAGGER;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 clk each
+    }
+#endif
+#if MOFO_GEMM_PRIO
+    {   // experiment: distinct issue priority per resident wave slot, to break the lock-step of co-resident blocks
+        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;   // HW_ID.wave_id[1:0]
+        if (slot == 0) __builtin_amdgcn_s_setprio(3);
+        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
+        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
+    }
+#endif
     int gi = 0;
 #pragma unroll
     for (int k = 1; k < MAXG; ++k)
@@ -170,6 +207,7 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     if (nk > 0) stage(0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    MOFO_TRACE(1);
     if constexpr (VAR == 0) {
         int cur = 0;
         for (int t = 0; t < nk; ++t) {
@@ -233,6 +271,7 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
         }
     }
 
+    MOFO_TRACE(2);
     if constexpr (CAN_COLSUM) {
         if (do_colsum && lane < 16) {   // D[n][m]: every row n holds the same sum; lanes 0..15 hold m = 16 i + lane in element 0
 #pragma unroll
@@ -244,6 +283,15 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     }
     // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
     // VAR 0 stages the wave's whole 64x64 f32 tile (16 KiB per wave); VAR 1 has 32 KiB of LDS and stages 32 rows per pass.
+    // The staging regions are wave-private and every wave is past the main loop's last barrier, so no block barrier is
+    // needed here: a wave's DS operations execute in order, and the four waves drift apart instead of storing in step.
+    // Per-block phase stamps (tools/gemm_trace.py) showed what the first version of this epilogue cost: hipcc put an
+    // `s_waitcnt vmcnt(0)` in front of every row group (the per-row bounds checks split the loop into basic blocks and the
+    // bias loads stayed "possibly pending"), so every store waited for the previous store's acknowledge, and the
+    // residual / pre-activation loads sat inside the loop, one HBM round trip per row group: 5k / 16k / 25k clk for the
+    // bf16 / dGELU / residual epilogues of a 13k-clk K=384 main loop.  Hence: (1) tiles that lie wholly inside C take a
+    // branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of CH row groups, the
+    // first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
     constexpr int PASSES = (VAR == 0) ? 1 : 2;
     constexpr int WROWS = 16 * MI;              // rows of the wave tile
     constexpr int PROWS = WROWS / PASSES;       // ... per pass
@@ -251,9 +299,9 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     float* ep = (float*)smem + wave * (PROWS * 64);
     const int mb = m0 + wm * WROWS, nb = n0 + wn * 64;
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
-#pragma unroll
-    for (int ps = 0; ps < PASSES; ++ps) {
-        if (ps > 0) __syncthreads();            // previous pass fully read before the staging area is rewritten
+    const bool full_tile = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
+
+    auto stage_acc = [&](int ps) {
 #pragma unroll
         for (int ii = 0; ii < MI / PASSES; ++ii) {
             const int i = ps * (MI / PASSES) + ii;
@@ -264,43 +312,72 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
                 *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
             }
         }
-        __syncthreads();
-        const int mp = mb + ps * PROWS;         // first global row of this pass
-        if constexpr (OUT_BF16) {
-            const int cg = lane & 7;
-            const int n = nb + cg * 8;
-            if (n < p.N) {
-                f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) {
-                    b0 = *(const f32x4*)(p.bias + n);
-                    b1 = *(const f32x4*)(p.bias + n + 4);
-                }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if constexpr (OUT_BF16) {
+        const int cg = lane & 7;
+        const int n = nb + cg * 8;
+        const bool ncol = n < p.N;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol) {
+            b0 = *(const f32x4*)(p.bias + n);
+            b1 = *(const f32x4*)(p.bias + n + 4);
+        }
+        constexpr int NIT = PROWS / 8;          // row groups (8 rows x 128 B per wave-instruction) per pass
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-                for (int it = 0; it < PROWS / 8; ++it) {
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int mp = mb + ps * PROWS;         // first global row of this pass
+                u32x4 h[NIT];
+                if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int m = mp + it * 8 + (lane >> 3);
+                        h[it] = u32x4{0u, 0u, 0u, 0u};
+                        if (FULL || (ncol && m < p.M)) h[it] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                    }
+                }
+                stage_acc(ps);
+                if (ps == 0) MOFO_TRACE(3);
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
                     const int r = it * 8 + (lane >> 3);
                     const int m = mp + r;
-                    if (m >= p.M) continue;
                     f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
                     f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
                     v0 += b0;
                     v1 += b1;
                     if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
-                        const u32x4 h = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
-                        v0[0] *= dgelu_erf(bf16lo_to_f32(h[0])); v0[1] *= dgelu_erf(bf16hi_to_f32(h[0]));
-                        v0[2] *= dgelu_erf(bf16lo_to_f32(h[1])); v0[3] *= dgelu_erf(bf16hi_to_f32(h[1]));
-                        v1[0] *= dgelu_erf(bf16lo_to_f32(h[2])); v1[1] *= dgelu_erf(bf16hi_to_f32(h[2]));
-                        v1[2] *= dgelu_erf(bf16lo_to_f32(h[3])); v1[3] *= dgelu_erf(bf16hi_to_f32(h[3]));
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2 d = dgelu_erf2((f32x2){bf16lo_to_f32(h[it][q]), bf16hi_to_f32(h[it][q])});
+                            if (q < 2) { v0[2 * q] *= d[0]; v0[2 * q + 1] *= d[1]; }
+                            else       { v1[2 * q - 4] *= d[0]; v1[2 * q - 3] *= d[1]; }
+                        }
                     }
                     const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-                    *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                    const bool ok = FULL || (ncol && m < p.M);
+                    if (ok) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
                     if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
-                        const u32x4 g = {pack_bf16x2(gelu_erf(v0[0]), gelu_erf(v0[1])), pack_bf16x2(gelu_erf(v0[2]), gelu_erf(v0[3])),
-                                         pack_bf16x2(gelu_erf(v1[0]), gelu_erf(v1[1])), pack_bf16x2(gelu_erf(v1[2]), gelu_erf(v1[3]))};
-                        *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
+                        const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
+                        const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
+                        const u32x4 g = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
+                        if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
                     }
                 }
+                __builtin_amdgcn_wave_barrier();
             }
-        } else if (EPI == MOFO_EPI_F32 && p.atomic) {
+        };
+        if (full_tile) run(std::true_type{});
+        else run(std::false_type{});
+    } else if (EPI == MOFO_EPI_F32 && p.atomic) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int mp = mb + ps * PROWS;
+            stage_acc(ps);
+            if (ps == 0) MOFO_TRACE(3);
             // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
             const int n = nb + lane;
             if (n < p.N) {
@@ -311,31 +388,70 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
                     dst += p.ldc;
                 }
             }
-        } else {
-            const int c4 = lane & 15;
-            const int n = nb + c4 * 4;
-            if (n < p.N) {
-                f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-                if (p.bias) bv = *(const f32x4*)(p.bias + n);
-#pragma unroll
-                for (int it = 0; it < PROWS / 4; ++it) {
-                    const int r = it * 4 + (lane >> 4);
-                    const int m = mp + r;
-                    if (m >= p.M) continue;
-                    f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
-                    v += bv;
-                    size_t orow = m;
-                    if constexpr (EPI == MOFO_EPI_RESID_F32) {
-                        v += *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
-                    } else if constexpr (EPI == MOFO_EPI_POS_F32) {
-                        orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
-                        v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
-                    }
-                    *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
-                }
-            }
+            __builtin_amdgcn_wave_barrier();
         }
+    } else {
+        const int c4 = lane & 15;
+        const int n = nb + c4 * 4;
+        const bool ncol = n < p.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol) bv = *(const f32x4*)(p.bias + n);
+        constexpr int NIT = PROWS / 4;          // row groups (4 rows x 256 B per wave-instruction) per pass
+        constexpr int CH = 8;                   // row groups per residual prefetch chunk (32 VGPRs)
+        static_assert(NIT % CH == 0 || NIT < CH, "chunking");
+        constexpr int NCH = NIT < CH ? 1 : NIT / CH, CHN = NIT < CH ? NIT : CH;
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+            for (int ps = 0; ps < PASSES; ++ps) {
+                const int mp = mb + ps * PROWS;
+                f32x4 rr[2][CHN];
+                auto load_chunk = [&](int c, f32x4* dst) {
+                    if constexpr (EPI == MOFO_EPI_RESID_F32) {
+#pragma unroll
+                        for (int k = 0; k < CHN; ++k) {
+                            const int m = mp + (c * CHN + k) * 4 + (lane >> 4);
+                            dst[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            if (FULL || (ncol && m < p.M)) dst[k] = *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+                        }
+                    }
+                };
+                load_chunk(0, rr[0]);
+                stage_acc(ps);
+                if (ps == 0) MOFO_TRACE(3);
+#pragma unroll
+                for (int c = 0; c < NCH; ++c) {
+                    if (c + 1 < NCH) load_chunk(c + 1, rr[(c + 1) & 1]);
+#pragma unroll
+                    for (int k = 0; k < CHN; ++k) {
+                        const int r = (c * CHN + k) * 4 + (lane >> 4);
+                        const int m = mp + r;
+                        const bool ok = FULL || (ncol && m < p.M);
+                        f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
+                        v += bv;
+                        size_t orow = m;
+                        if constexpr (EPI == MOFO_EPI_RESID_F32) {
+                            v += rr[c & 1][k];
+                        } else if constexpr (EPI == MOFO_EPI_POS_F32) {
+                            if (ok) {
+                                orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
+                                v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
+                            }
+                        }
+                        if (ok) *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        if (full_tile) run(std::true_type{});
+        else run(std::false_type{});
     }
+    MOFO_TRACE(4);
+#ifdef MOFO_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
+    MOFO_TRACE(5);
+#endif
 }
 
 // Which main-loop variant per (layouts, epilogue), from in-step A/B timing on MI355X (ViT-B, B=32; profiles/): the
@@ -461,6 +577,12 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
     }
     return dispatch(a[0].op, a[0].epilogue, g, mi, (hipStream_t)stream);
 }
+
+#ifdef MOFO_GEMM_TRACE
+extern "C" int mofo_debug_trace_read(void* dst_host, size_t bytes) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
+}
+#endif
 
 extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
     if (!a) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null args");
