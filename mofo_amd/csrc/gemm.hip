@@ -5,13 +5,13 @@
 //   TN  C[m,n] = sum_k A[k,m] * B[k,n]     wgrad  (dY^T @ X); both operands reduction-strided
 //
 // Tile 128x128x64, 256 threads = 4 waves (2x2), each wave 64x64 = 4x4 tiles of v_mfma_f32_16x16x32_bf16.
-// Operands go HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip), two LDS buffers.
+// Operands go HBM -> LDS with buffer_load_dwordx4 ... lds (no VGPR round trip; SRD + 32-bit lane offset + SGPR tile offset).
 //   ROW operand (reduction contiguous): LDS image [128 rows][64 k] bf16 (128-B rows); 16-B chunk c of row r
 //       sits at chunk position c ^ (r & 7)  -> ds_read_b128 fragment reads are bank-conflict free.
 //   COL operand (reduction strided):   LDS image [64 k][128 cols] bf16 (256-B rows); 32-B unit u of k-row r
 //       sits at unit position u ^ key(r), key(r) = (r&3) | ((r>>3)&1)<<2  -> ds_read_b64_tr_b16 (hardware
 //       transpose read) fragment reads are bank-conflict free.
-//   LDS-DMA writes are lane-linear, so both swizzles are applied to the per-lane SOURCE address.
+//   LDS-DMA writes are lane-linear, so both swizzles are applied to the per-lane SOURCE offset.
 // The MFMA is issued as mfma(Bfrag, Afrag) so that a lane ends up holding 4 CONSECUTIVE n of one m:
 //   acc[mt][nt][j] = C[m0 + 16 mt + (lane & 15)][n0 + 16 nt + 4 (lane >> 4) + j]
 // EPILOGUE: the fragment layout touches 16 different rows per store instruction (32-B pieces), which made the short-K
@@ -33,7 +33,6 @@ constexpr int BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;  // 16 KiB per operand tile
 constexpr int OPL_ROW = 0, OPL_COL = 1;
 
-__device__ __attribute__((aligned(256))) unsigned int g_zero_page[64];  // 256 B of zeros: source of padded k-rows
 
 struct GemmP {
     const bf16_t* A; const bf16_t* B;
@@ -56,9 +55,6 @@ struct GroupP {
 };
 
 // Debug build only (-DMOFO_GEMM_TRACE, tools/gemm_trace.py): per-block phase timestamps (s_memtime) + the CU the block ran on.
-#ifndef MOFO_GEMM_PRIO
-#define MOFO_GEMM_PRIO 0
-#endif
 #ifdef MOFO_GEMM_TRACE
 __device__ unsigned long long g_trace[1 << 19];
 #define MOFO_TRACE(slot)                                                                          \
@@ -70,39 +66,55 @@ __device__ unsigned long long g_trace[1 << 19];
         if (threadIdx.x == 0 && blockIdx.x < (1 << 16))                                           \
             g_trace[blockIdx.x * 8 + 7] = ((unsigned long long)__builtin_amdgcn_s_getreg(6164) << 32) | __builtin_amdgcn_s_getreg(63492); \
     } while (0)
+// stamps inside main-loop iteration 2 of wave 0 (slots 0..5 of g_trace_it)
+__device__ unsigned long long g_trace_it[1 << 19];
+#define MOFO_TRACE_IT(t, slot)                                                                    \
+    do {                                                                                          \
+        if ((t) == 2 && threadIdx.x == 0 && blockIdx.x < (1 << 16)) g_trace_it[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define MOFO_TRACE(slot)
 #define MOFO_TRACE_ID()
+#define MOFO_TRACE_IT(t, slot)
 #endif
 
 __device__ __forceinline__ int col_key(int krow) { return (krow & 3) | (((krow >> 3) & 1) << 2); }
 
-// Issue the LDS-DMA loads of one operand tile.  `dim` = extent of the non-reduction index, `kend` = end of the
-// reduction range of this block.
-template <int LAYOUT, int NI>   // NI wave-instructions per wave: 4 for a 128-row (ROW) / 128-column (COL) tile, 2 for 64 rows
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int ld, int dim, int d0, int k0, int kend,
-                                           unsigned char* lds_tile, int wave, int lane) {
+// Issue the LDS-DMA loads of one operand tile through a buffer resource (SRD): `buffer_load_dwordx4 ... offen lds` takes the per-lane part of the
+// address as ONE 32-bit VGPR offset that is the same for every piece and every k-stage, the tile / piece / k position as a
+// wave-uniform SGPR offset, and range-checks against the operand's extent (rows beyond M or N and k-rows beyond K read as
+// zeros: no clamps, no zero page).  The first version used flat `global_load_lds` with a 64-bit per-lane address per piece: 16
+// address VGPRs per operand live across the main loop, and 2-3x the issue time for the reduction-strided (COL) pieces.
+// Piece i of a tile is 1 KiB: ROW rows 8i..8i+7 (8 lanes x 16 B per row), COL k-rows 4i..4i+3 (16 lanes x 16 B per row).
+// ROW: voff = ((lane>>3) * ld + ((lane&7) ^ ((lane>>3)&7)) * 8) * 2 bytes.
+// COL: the swizzle key of a piece's k-rows has one bit that depends on the piece, (i>>1)&1, so two offsets alternate:
+//      voff[h] = ((lane>>4) * ld + gch_h * 8) * 2,  gch_h = ((((lane&15)>>1) ^ ((lane>>4) | h<<2)) << 1) | (lane&1).
+template <int LAYOUT>
+__device__ __forceinline__ void srd_lane_offsets(int ld, int lane, int& v0, int& v1) {
+    if constexpr (LAYOUT == OPL_ROW) {
+        v0 = v1 = ((lane >> 3) * ld + (((lane & 7) ^ ((lane >> 3) & 7)) << 3)) * 2;
+    } else {
+        const int cpos = lane & 15, kq = lane >> 4;
+        const int g0 = ((((cpos >> 1) ^ kq) << 1) | (cpos & 1));
+        const int g1 = ((((cpos >> 1) ^ (kq | 4)) << 1) | (cpos & 1));
+        v0 = (kq * ld + g0 * 8) * 2;
+        v1 = (kq * ld + g1 * 8) * 2;
+    }
+}
+template <int LAYOUT, int NI>
+__device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int v0, int v1, int ld, int d0, int k0,
+                                               unsigned char* lds_tile, int wave_u) {
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-        const int i = wave * NI + j;  // wave-instruction index, 1 KiB each
-        const bf16_t* src;
+        const int i = wave_u * NI + j;
         if constexpr (LAYOUT == OPL_ROW) {
-            const int rl = 8 * i + (lane >> 3);
-            int row = d0 + rl;
-            row = row < dim ? row : dim - 1;  // clamp: garbage rows are never stored
-            const int gch = (lane & 7) ^ ((lane >> 3) & 7);
-            src = base + (size_t)row * ld + k0 + gch * 8;
+            const int soff = ((d0 + 8 * i) * ld + k0) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, soff, 0, 0);
         } else {
-            const int kr = 4 * i + (lane >> 4);
-            const int cpos = lane & 15;
-            const int gch = ((((cpos >> 1) ^ col_key(kr)) << 1) | (cpos & 1));
-            int col = d0 + gch * 8;
-            col = col <= dim - 8 ? col : dim - 8;
-            const int k = k0 + kr;
-            src = (k < kend) ? base + (size_t)k * ld + col
-                             : (const bf16_t*)((const unsigned char*)g_zero_page + cpos * 16);
+            static_assert(LAYOUT == OPL_ROW || NI == 4, "piece parity below assumes 4 pieces per wave");
+            const int soff = ((k0 + 4 * i) * ld + d0) * 2;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, soff, 0, 0);
         }
-        __builtin_amdgcn_global_load_lds(GLB_PTR(src), LDS_PTR(lds_tile + i * 1024), 16, 0, 0);
     }
 }
 
@@ -128,6 +140,168 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
     }
 }
 
+// EPILOGUE of one wave's (16 MI) x 64 accumulator tile, through a wave-private LDS staging area `ep` of PROWS x 64 f32.
+// The staging area is wave-private and a wave's DS operations execute in order, so no block barrier is needed: the four
+// waves drift apart instead of storing in step.  Per-block phase stamps (tools/gemm_trace.py) showed what the first
+// version of this epilogue cost: hipcc put an `s_waitcnt vmcnt(0)` in front of every row group (the per-row bounds checks
+// split the loop into basic blocks and the bias loads stayed "possibly pending"), so every store waited for the previous
+// store's acknowledge, and the residual / pre-activation loads sat inside the loop, one HBM round trip per row group:
+// 5k / 16k / 25k clk for the bf16 / dGELU / residual epilogues beside a 13k-clk K=384 main loop.  Hence: (1) tiles that
+// lie wholly inside C take a branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of
+// up to 32 VGPRs, the first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
+template <int EPI, int MI, int PASSES>
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int m0, int n0, int wm, int wn, int lane) {
+    constexpr int WROWS = 16 * MI;              // rows of the wave tile
+    constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
+    constexpr int BMT = 32 * MI;
+    const int mb = m0 + wm * WROWS, nb = n0 + wn * 64;
+    constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
+    const bool full_tile = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
+
+    auto stage_acc = [&](int ps) {
+#pragma unroll
+        for (int ii = 0; ii < MI / PASSES; ++ii) {
+            const int i = ps * (MI / PASSES) + ii;
+            const int r = 16 * ii + (lane & 15);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c4 = 4 * j + (lane >> 4);
+                *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    };
+
+    if constexpr (OUT_BF16) {
+        const int cg = lane & 7;
+        const int n = nb + cg * 8;
+        const bool ncol = n < p.N;
+        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol) {
+            b0 = *(const f32x4*)(p.bias + n);
+            b1 = *(const f32x4*)(p.bias + n + 4);
+        }
+        constexpr int NIT = PROWS / 8;          // row groups (8 rows x 128 B per wave-instruction) per pass
+        constexpr int NG = WROWS / 8;           // ... per wave tile; the pre-activation rows of all of them are fetched up front
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            u32x4 h[NG];
+            if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    const int m = mb + g * 8 + (lane >> 3);
+                    h[g] = u32x4{0u, 0u, 0u, 0u};
+                    if (FULL || (ncol && m < p.M)) h[g] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g % NIT == 0) {
+                    if (g) __builtin_amdgcn_wave_barrier();
+                    stage_acc(g / NIT);
+                    if (g == 0) MOFO_TRACE(3);
+                }
+                const int r = (g % NIT) * 8 + (lane >> 3);
+                const int m = mb + g * 8 + (lane >> 3);
+                f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
+                f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
+                v0 += b0;
+                v1 += b1;
+                if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x2 d = dgelu_erf2((f32x2){bf16lo_to_f32(h[g][q]), bf16hi_to_f32(h[g][q])});
+                        if (q < 2) { v0[2 * q] *= d[0]; v0[2 * q + 1] *= d[1]; }
+                        else       { v1[2 * q - 4] *= d[0]; v1[2 * q - 3] *= d[1]; }
+                    }
+                }
+                const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
+                const bool ok = FULL || (ncol && m < p.M);
+                if (ok) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
+                    const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
+                    const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
+                    const u32x4 gg = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
+                    if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = gg;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (full_tile) run(std::true_type{});
+        else run(std::false_type{});
+    } else if (EPI == MOFO_EPI_F32 && p.atomic) {
+#pragma unroll
+        for (int ps = 0; ps < PASSES; ++ps) {
+            const int mp = mb + ps * PROWS;
+            stage_acc(ps);
+            if (ps == 0) MOFO_TRACE(3);
+            // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
+            const int n = nb + lane;
+            if (n < p.N) {
+                float* dst = (float*)p.C + (size_t)mp * p.ldc + n;
+                const int rows = min(PROWS, p.M - mp);
+                for (int r = 0; r < rows; ++r) {
+                    atomicAdd(dst, ep[r * 64 + ((((lane >> 2) ^ (r & 15)) << 2) | (lane & 3))]);
+                    dst += p.ldc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        const int c4 = lane & 15;
+        const int n = nb + c4 * 4;
+        const bool ncol = n < p.N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && ncol) bv = *(const f32x4*)(p.bias + n);
+        constexpr int NIT = PROWS / 4;          // row groups (4 rows x 256 B per wave-instruction) per pass
+        constexpr int NG = WROWS / 4;           // ... per wave tile
+        constexpr int CH = NG < 8 ? NG : 8;     // row groups per residual prefetch chunk (32 VGPRs)
+        static_assert(NG % CH == 0, "chunking");
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            f32x4 rr[2][CH];
+            auto load_chunk = [&](int c, f32x4* dst) {
+                if constexpr (EPI == MOFO_EPI_RESID_F32) {
+#pragma unroll
+                    for (int k = 0; k < CH; ++k) {
+                        const int m = mb + (c * CH + k) * 4 + (lane >> 4);
+                        dst[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (FULL || (ncol && m < p.M)) dst[k] = *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+                    }
+                }
+            };
+            load_chunk(0, rr[0]);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g % NIT == 0) {
+                    if (g) __builtin_amdgcn_wave_barrier();
+                    stage_acc(g / NIT);
+                    if (g == 0) MOFO_TRACE(3);
+                }
+                if (g % CH == 0 && g + CH < NG) load_chunk(g / CH + 1, rr[(g / CH + 1) & 1]);
+                const int r = (g % NIT) * 4 + (lane >> 4);
+                const int m = mb + g * 4 + (lane >> 4);
+                const bool ok = FULL || (ncol && m < p.M);
+                f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
+                v += bv;
+                size_t orow = m;
+                if constexpr (EPI == MOFO_EPI_RESID_F32) {
+                    v += rr[(g / CH) & 1][g % CH];
+                } else if constexpr (EPI == MOFO_EPI_POS_F32) {
+                    if (ok) {
+                        orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
+                        v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
+                    }
+                }
+                if (ok) *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        if (full_tile) run(std::true_type{});
+        else run(std::false_type{});
+    }
+}
+
 // VAR 0: two LDS stages (64 KiB, 2 blocks/CU).  VAR 1: ONE LDS stage (32 KiB, 3 blocks/CU by VGPRs) with register
 // double-buffering: all fragments of tile t are read into VGPRs, barrier, tile t+1's LDS-DMA is issued into the same
 // LDS buffer and flies while the 32 MFMAs of tile t run from registers.  More resident blocks per CU let one block's
@@ -145,20 +319,6 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     const int wm = wave >> 1, wn = wave & 1;
     MOFO_TRACE(0);
     MOFO_TRACE_ID();
-#ifdef MOFO_GEMM_STAGGER
-    if (blockIdx.x >= 256 && blockIdx.x < 768) {   // experiment: one-time phase offset of the 2nd/3rd resident block of every CU
-        const int n = (blockIdx.x >> 8) * MOFO_GEMM_STAGGER;
-        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);   // 1024 clk each
-    }
-#endif
-#if MOFO_GEMM_PRIO
-    {   // experiment: distinct issue priority per resident wave slot, to break the lock-step of co-resident blocks
-        const unsigned slot = __builtin_amdgcn_s_getreg((3 << 11) | 4) & 3;   // HW_ID.wave_id[1:0]
-        if (slot == 0) __builtin_amdgcn_s_setprio(3);
-        else if (slot == 1) __builtin_amdgcn_s_setprio(2);
-        else if (slot == 2) __builtin_amdgcn_s_setprio(1);
-    }
-#endif
     int gi = 0;
 #pragma unroll
     for (int k = 1; k < MAXG; ++k)
@@ -198,10 +358,19 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
 #pragma unroll
     for (int e = 0; e < 8; ++e) ones[e] = (__bf16)1.0f;
 
+    // operand extents for the range check: rows beyond M / N and k-rows beyond this block's k-range read as zeros
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const size_t ext_a = (LA == OPL_ROW ? ((size_t)p.M - 1) * p.lda + kend : ((size_t)kend - 1) * p.lda + p.M) * 2;
+    const size_t ext_b = (LB == OPL_ROW ? ((size_t)p.N - 1) * p.ldb + kend : ((size_t)kend - 1) * p.ldb + p.N) * 2;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)ext_a, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)ext_b, 0x00020000);
+    int va0, va1, vb0, vb1;
+    srd_lane_offsets<LA>(p.lda, lane, va0, va1);
+    srd_lane_offsets<LB>(p.ldb, lane, vb0, vb1);
     auto stage = [&](int t, int buf) {
         unsigned char* ta = smem + buf * STG;
-        stage_tile<LA, MI>(p.A, p.lda, p.M, m0, kbeg + t * BK, kend, ta, wave, lane);
-        stage_tile<LB, 4>(p.B, p.ldb, p.N, n0, kbeg + t * BK, kend, ta + A_BYTES, wave, lane);
+        stage_tile_srd<LA, (LA == OPL_ROW ? MI : 4)>(ra, va0, va1, p.lda, m0, kbeg + t * BK, ta, wave_u);
+        stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, kbeg + t * BK, ta + A_BYTES, wave_u);
     };
 
     if (nk > 0) stage(0, 0);
@@ -242,6 +411,7 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
         const unsigned char* tb = smem + A_BYTES;
         for (int t = 0; t < nk; ++t) {
             bf16x8 af[2][MI], bfr[2][4];
+            MOFO_TRACE_IT(t, 0);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -250,8 +420,11 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
                 for (int i = 0; i < 4; ++i) bfr[ks][i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            MOFO_TRACE_IT(t, 1);
             __builtin_amdgcn_s_barrier();          // every wave holds tile t in registers: the LDS buffer is free
+            MOFO_TRACE_IT(t, 2);
             if (t + 1 < nk) stage(t + 1, 0);       // tile t+1 flies while tile t is multiplied from registers
+            MOFO_TRACE_IT(t, 3);
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
@@ -266,8 +439,11 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
                     }
                 }
             }
+            MOFO_TRACE_IT(t, 4);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MOFO_TRACE_IT(t, 5);
             __builtin_amdgcn_s_barrier();          // tile t+1 landed and is visible to every wave
+            MOFO_TRACE_IT(t, 6);
         }
     }
 
@@ -283,170 +459,9 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     }
     // ------------------------------------------------------------------ epilogue (through LDS, whole row segments)
     // VAR 0 stages the wave's whole 64x64 f32 tile (16 KiB per wave); VAR 1 has 32 KiB of LDS and stages 32 rows per pass.
-    // The staging regions are wave-private and every wave is past the main loop's last barrier, so no block barrier is
-    // needed here: a wave's DS operations execute in order, and the four waves drift apart instead of storing in step.
-    // Per-block phase stamps (tools/gemm_trace.py) showed what the first version of this epilogue cost: hipcc put an
-    // `s_waitcnt vmcnt(0)` in front of every row group (the per-row bounds checks split the loop into basic blocks and the
-    // bias loads stayed "possibly pending"), so every store waited for the previous store's acknowledge, and the
-    // residual / pre-activation loads sat inside the loop, one HBM round trip per row group: 5k / 16k / 25k clk for the
-    // bf16 / dGELU / residual epilogues of a 13k-clk K=384 main loop.  Hence: (1) tiles that lie wholly inside C take a
-    // branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of CH row groups, the
-    // first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
     constexpr int PASSES = (VAR == 0) ? 1 : 2;
-    constexpr int WROWS = 16 * MI;              // rows of the wave tile
-    constexpr int PROWS = WROWS / PASSES;       // ... per pass
-    static_assert(4 * PROWS * 64 * 4 <= (VAR == 0 ? 2 : 1) * STG, "epilogue staging must fit the main-loop LDS");
-    float* ep = (float*)smem + wave * (PROWS * 64);
-    const int mb = m0 + wm * WROWS, nb = n0 + wn * 64;
-    constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
-    const bool full_tile = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
-
-    auto stage_acc = [&](int ps) {
-#pragma unroll
-        for (int ii = 0; ii < MI / PASSES; ++ii) {
-            const int i = ps * (MI / PASSES) + ii;
-            const int r = 16 * ii + (lane & 15);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int c4 = 4 * j + (lane >> 4);
-                *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    };
-
-    if constexpr (OUT_BF16) {
-        const int cg = lane & 7;
-        const int n = nb + cg * 8;
-        const bool ncol = n < p.N;
-        f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && ncol) {
-            b0 = *(const f32x4*)(p.bias + n);
-            b1 = *(const f32x4*)(p.bias + n + 4);
-        }
-        constexpr int NIT = PROWS / 8;          // row groups (8 rows x 128 B per wave-instruction) per pass
-        auto run = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int mp = mb + ps * PROWS;         // first global row of this pass
-                u32x4 h[NIT];
-                if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
-#pragma unroll
-                    for (int it = 0; it < NIT; ++it) {
-                        const int m = mp + it * 8 + (lane >> 3);
-                        h[it] = u32x4{0u, 0u, 0u, 0u};
-                        if (FULL || (ncol && m < p.M)) h[it] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
-                    }
-                }
-                stage_acc(ps);
-                if (ps == 0) MOFO_TRACE(3);
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int r = it * 8 + (lane >> 3);
-                    const int m = mp + r;
-                    f32x4 v0 = *(const f32x4*)(ep + r * 64 + (((2 * cg) ^ (r & 15)) << 2));
-                    f32x4 v1 = *(const f32x4*)(ep + r * 64 + (((2 * cg + 1) ^ (r & 15)) << 2));
-                    v0 += b0;
-                    v1 += b1;
-                    if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x2 d = dgelu_erf2((f32x2){bf16lo_to_f32(h[it][q]), bf16hi_to_f32(h[it][q])});
-                            if (q < 2) { v0[2 * q] *= d[0]; v0[2 * q + 1] *= d[1]; }
-                            else       { v1[2 * q - 4] *= d[0]; v1[2 * q - 3] *= d[1]; }
-                        }
-                    }
-                    const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
-                    const bool ok = FULL || (ncol && m < p.M);
-                    if (ok) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
-                    if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
-                        const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
-                        const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
-                        const u32x4 g = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
-                        if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = g;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        if (full_tile) run(std::true_type{});
-        else run(std::false_type{});
-    } else if (EPI == MOFO_EPI_F32 && p.atomic) {
-#pragma unroll
-        for (int ps = 0; ps < PASSES; ++ps) {
-            const int mp = mb + ps * PROWS;
-            stage_acc(ps);
-            if (ps == 0) MOFO_TRACE(3);
-            // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
-            const int n = nb + lane;
-            if (n < p.N) {
-                float* dst = (float*)p.C + (size_t)mp * p.ldc + n;
-                const int rows = min(PROWS, p.M - mp);
-                for (int r = 0; r < rows; ++r) {
-                    atomicAdd(dst, ep[r * 64 + ((((lane >> 2) ^ (r & 15)) << 2) | (lane & 3))]);
-                    dst += p.ldc;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        const int c4 = lane & 15;
-        const int n = nb + c4 * 4;
-        const bool ncol = n < p.N;
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias && ncol) bv = *(const f32x4*)(p.bias + n);
-        constexpr int NIT = PROWS / 4;          // row groups (4 rows x 256 B per wave-instruction) per pass
-        constexpr int CH = 8;                   // row groups per residual prefetch chunk (32 VGPRs)
-        static_assert(NIT % CH == 0 || NIT < CH, "chunking");
-        constexpr int NCH = NIT < CH ? 1 : NIT / CH, CHN = NIT < CH ? NIT : CH;
-        auto run = [&](auto full_tag) {
-            constexpr bool FULL = decltype(full_tag)::value;
-#pragma unroll
-            for (int ps = 0; ps < PASSES; ++ps) {
-                const int mp = mb + ps * PROWS;
-                f32x4 rr[2][CHN];
-                auto load_chunk = [&](int c, f32x4* dst) {
-                    if constexpr (EPI == MOFO_EPI_RESID_F32) {
-#pragma unroll
-                        for (int k = 0; k < CHN; ++k) {
-                            const int m = mp + (c * CHN + k) * 4 + (lane >> 4);
-                            dst[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            if (FULL || (ncol && m < p.M)) dst[k] = *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
-                        }
-                    }
-                };
-                load_chunk(0, rr[0]);
-                stage_acc(ps);
-                if (ps == 0) MOFO_TRACE(3);
-#pragma unroll
-                for (int c = 0; c < NCH; ++c) {
-                    if (c + 1 < NCH) load_chunk(c + 1, rr[(c + 1) & 1]);
-#pragma unroll
-                    for (int k = 0; k < CHN; ++k) {
-                        const int r = (c * CHN + k) * 4 + (lane >> 4);
-                        const int m = mp + r;
-                        const bool ok = FULL || (ncol && m < p.M);
-                        f32x4 v = *(const f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2));
-                        v += bv;
-                        size_t orow = m;
-                        if constexpr (EPI == MOFO_EPI_RESID_F32) {
-                            v += rr[c & 1][k];
-                        } else if constexpr (EPI == MOFO_EPI_POS_F32) {
-                            if (ok) {
-                                orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
-                                v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
-                            }
-                        }
-                        if (ok) *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        };
-        if (full_tile) run(std::true_type{});
-        else run(std::false_type{});
-    }
+    static_assert(4 * (16 * MI / PASSES) * 64 * 4 <= (VAR == 0 ? 2 : 1) * STG, "epilogue staging must fit the main-loop LDS");
+    epilogue<EPI, MI, PASSES>(p, acc, (float*)smem + wave * ((16 * MI / PASSES) * 64), m0, n0, wm, wn, lane);
     MOFO_TRACE(4);
 #ifdef MOFO_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -454,37 +469,147 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
 #endif
 }
 
-// Which main-loop variant per (layouts, epilogue), from in-step A/B timing on MI355X (ViT-B, B=32; profiles/): the
-// register-double-buffered single-stage form (3 blocks/CU) wins for dgrad (NN) and the plain bf16 NT GEMMs; the
-// two-stage form wins for wgrad (TN: VAR 1 spills at 168 VGPRs) and for the f32 residual / GELU epilogues.
-// MOFO_GEMM_VARIANT=0|1 forces one form for measurements.
-template <int LA, int LB, int EPI>
-int gemm_variant() {
+// VAR 2: PERSISTENT form of VAR 1 for the single-problem NT / NN GEMMs (no split-K).  Phase stamps of VAR 1 at the decoder
+// shapes (K = 384: six k-iterations per tile) showed 13-18 % of a block's life spent waiting for its FIRST operand tile
+// (kernel-argument fetch + LDS-DMA issue + HBM/L2 latency) with nothing else to do.  Here at most 3 x 256 blocks are
+// launched and each walks tiles w, w + grid, w + 2 grid, ...: the first k-stage of the NEXT tile is issued from the last
+// k-iteration of the current one and lands while the epilogue runs.  That needs an epilogue staging area apart from the
+// operand stage: 16 rows x 64 f32 per wave (16 KiB per block, MI passes), 48 KiB of LDS per block -> still 3 blocks / CU.
+template <int LA, int LB, int EPI, int MI>
+__global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int total) {
+    static_assert(LA == OPL_ROW, "persistent form is built for the ROW A operand (NT / NN)");
+    constexpr int BMT = 32 * MI;
+    constexpr int A_BYTES = BMT * 64 * 2;
+    constexpr int STG = A_BYTES + TILE_BYTES;
+    constexpr int EP_BYTES = 4 * 16 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STG + EP_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    MOFO_TRACE(0);
+    MOFO_TRACE_ID();
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nk = p.K / BK;
+    // XCD-aware order over the virtual grid of `total` one-tile blocks (grid is `total` or a multiple of 8, so a block's
+    // tiles all have its own index mod 8 = its XCD): each XCD walks a contiguous run of tiles, n fastest
+    auto decode = [&](int w, int& m0, int& n0) {
+        const int q = total >> 3, r = total & 7, xcd = w & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+        m0 = (wg / tiles_n) * BMT;
+        n0 = (wg % tiles_n) * BN;
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    // extents: A is [M, K] (ROW); B is [N, K] (ROW, NT) or [K, N] (COL, NN)
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((((size_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, (int)((LB == OPL_ROW ? ((size_t)p.N - 1) * p.ldb + p.K : ((size_t)p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
+    int va0, va1, vb0, vb1;
+    srd_lane_offsets<LA>(p.lda, lane, va0, va1);
+    srd_lane_offsets<LB>(p.ldb, lane, vb0, vb1);
+    auto stage = [&](int m0, int n0, int t) {
+        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, t * BK, smem, wave_u);
+        stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, t * BK, smem + A_BYTES, wave_u);
+    };
+    const unsigned char* ta = smem;
+    const unsigned char* tb = smem + A_BYTES;
+    float* ep = (float*)(smem + STG) + wave * (16 * 64);
+    int w = blockIdx.x, m0, n0;
+    decode(w, m0, n0);
+    stage(m0, n0, 0);
+    for (;;) {
+        const int wnext = w + (int)gridDim.x;
+        const bool has_next = wnext < total;
+        int m1 = 0, n1 = 0;
+        if (has_next) decode(wnext, m1, n1);
+        f32x4 acc[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first k-stage (and the previous epilogue's stores)
+        __builtin_amdgcn_s_barrier();
+        MOFO_TRACE(1);
+        for (int t = 0; t < nk; ++t) {
+            bf16x8 af[2][MI], bfr[2][4];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) af[ks][i] = read_frag<LA>(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bfr[ks][i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave holds k-stage t in registers: the LDS stage is free
+            if (t + 1 < nk) stage(m0, n0, t + 1);
+            else if (has_next) stage(m1, n1, 0);   // the next tile's first k-stage flies under this tile's epilogue
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+            if (t + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();      // k-stage t+1 landed and is visible to every wave
+            }
+        }
+        MOFO_TRACE(2);
+        epilogue<EPI, MI, MI>(p, acc, ep, m0, n0, wm, wn, lane);
+        MOFO_TRACE(4);
+        if (!has_next) break;
+        w = wnext;
+        m0 = m1;
+        n0 = n1;
+    }
+#ifdef MOFO_GEMM_TRACE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MOFO_TRACE(5);
+#endif
+}
+
+// Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
+// (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
+//   wgrad (TN)            VAR 1: 2.30 ms/step vs 2.69 for VAR 0 (3 blocks per CU; fits 168 VGPRs since the SRD staging)
+//   NT / NN, all epilogues VAR 2 (persistent): dgrad 2.06 vs 2.20 (VAR 1) / 2.36 (VAR 0); dGELU 0.98 / 1.05 / 1.14;
+//                          GELU 0.98 / 1.04 / 1.07; bf16 0.62 / 0.65 / 0.71
+//   ... except the f32-residual epilogue on grids that give a persistent block a single tile (encoder proj / fc2:
+//       480 64-row tiles): the two-stage VAR 0 is 5-8 % faster there; and the 2-launch pos-embedding epilogue (VAR 0).
+static int forced_variant() {
     static int forced = -2;
     if (forced == -2) {
         const char* e = getenv("MOFO_GEMM_VARIANT");
-        forced = e ? (atoi(e) != 0) : -1;
+        forced = e ? atoi(e) : -1;
     }
-    if (forced >= 0) return forced;
-    if (LA == OPL_ROW && LB == OPL_COL) return 1;
-    if (LA == OPL_ROW && LB == OPL_ROW && EPI == MOFO_EPI_BF16) return 1;
-    return 0;
+    return forced;
 }
 
 template <int LA, int LB, int EPI>
 int launch(const GroupP& g, int mi, hipStream_t s) {
-    const int var = gemm_variant<LA, LB, EPI>();
+    const int forced = forced_variant();
     const dim3 grid(g.start[g.count]), block(256);
     if constexpr (LA == OPL_ROW) {
-        if (mi == 2) {
+        const GemmP& p = g.p[0];
+        const int total = g.start[1];
+        // persistent form: one problem, no split-K / accumulate
+        const bool can_persist = g.count == 1 && !p.atomic && p.k_per_split >= p.K && EPI != MOFO_EPI_POS_F32;
+        int var = forced >= 0 ? forced : ((EPI == MOFO_EPI_RESID_F32 && total <= 768) || !can_persist ? 0 : 2);
+        if (var == 2 && !can_persist) var = 1;
+        if (var == 2) {
+            const dim3 pgrid(total < 768 ? total : 768);
+            if (mi == 2) hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 2>), pgrid, block, 0, s, p, total);
+            else hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 4>), pgrid, block, 0, s, p, total);
+        } else if (mi == 2) {
             if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 2>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 2>), grid, block, 0, s, g);
-            MOFO_CHECK_LAUNCH("mofo_gemm");
-            return MOFO_OK;
+        } else {
+            if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
         }
+    } else {
+        const int var = forced >= 0 ? (forced != 0) : 1;
+        if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
     }
-    if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
-    else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
     MOFO_CHECK_LAUNCH("mofo_gemm");
     return MOFO_OK;
 }
@@ -581,6 +706,9 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
 #ifdef MOFO_GEMM_TRACE
 extern "C" int mofo_debug_trace_read(void* dst_host, size_t bytes) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
+}
+extern "C" int mofo_debug_trace_it_read(void* dst_host, size_t bytes) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace_it), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
 }
 #endif
 

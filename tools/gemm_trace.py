@@ -87,3 +87,15 @@ t0 = ts[one, 0].min()
 blk = np.nonzero(buf.reshape(-1, 8)[:, 0] > 0)[0]
 for b in one[:12]:
     print("   ", blk[b], hwid[b] & 15, ts[b, 0] - t0, *d[b])
+
+# inside iteration 2 of the VAR 1 main loop (wave 0): frag reads | barrier | DMA issue | MFMA issue | vmcnt wait | barrier
+buf2 = np.zeros((1 << 16) * 8, dtype=np.uint64)
+lib.mofo_debug_trace_it_read.argtypes = [C.c_void_p, C.c_size_t]; lib.mofo_debug_trace_it_read.restype = C.c_int
+assert lib.mofo_debug_trace_it_read(buf2.ctypes.data, buf2.nbytes) == 0
+u = buf2.reshape(-1, 8)
+u = u[u[:, 0] > 0][:, :7].astype(np.int64)
+if len(u):
+    dd = np.diff(u, axis=1)
+    for i, n in enumerate(["read frags (LDS)", "barrier", "issue LDS-DMA of next tile", "issue 32 MFMAs", "wait vmcnt(0)", "barrier"]):
+        print(f"  it2: {n:28s} mean {dd[:, i].mean():8.0f}  p10 {np.percentile(dd[:, i], 10):8.0f}  p50 {np.percentile(dd[:, i], 50):8.0f}  p90 {np.percentile(dd[:, i], 90):8.0f} clk")
+    print(f"  it2: total {(u[:, 6] - u[:, 0]).mean():.0f} clk")
