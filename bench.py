@@ -6,8 +6,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 One step = what the reference's train_one_epoch does per batch (engine_for_pretraining.py:29-69,168-179) minus its PNG
-dump: lr/wd schedule write, target build + forward + MSE (fused), loss read-back + finite check, zero_grad, backward,
-gradient all-reduce (N>1, overlapped), global grad norm, AdamW, device sync.  Inputs are synthetic, generated straight
+dump: lr/wd schedule write, target build + forward + MSE (fused), zero_grad, backward, gradient all-reduce (N>1,
+overlapped), global grad norm, AdamW, loss read-back + finite check (issued while the backward runs, as the drop-in
+engine does; both of the reference's device syncs are kept), device sync.  Inputs are synthetic, generated straight
 into the model's device input buffers before the timed region.  Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -128,11 +129,11 @@ def main():
             if g["weight_decay"] > 0:
                 g["weight_decay"] = wd_sched[it]
         loss = wrapped.forward_loss(clips, mask_dev, True)
-        lv = loss.item()                                            # engine_for_pretraining.py:69 (sync #1)
+        opt.zero_grad()
+        scaler(loss, opt, clip_grad=None)                           # backward + grad-norm + AdamW enqueued ...
+        lv = loss.item()                                            # ... then the loss read (engine_for_pretraining.py:69, sync #1)
         if not math.isfinite(lv):
             raise SystemExit(f"loss is {lv}")
-        opt.zero_grad()
-        scaler(loss, opt, clip_grad=None)
         torch.cuda.synchronize()                                    # engine_for_pretraining.py:179 (sync #2)
         return lv
 

@@ -1,7 +1,7 @@
 """Drop-in for the reference's ``engine_for_pretraining.py``: ``train_one_epoch`` / ``train_one_epoch_BB`` with the
 reference's signature and returned meter dict.  Per step (engine_for_pretraining.py:29-69,168-208):
-  schedule writes -> batch to device -> [target build + forward + MSE] -> finite check -> zero_grad ->
-  loss_scaler(backward, grad norm / clip, optimizer step) -> meters.
+  schedule writes -> batch to device -> [target build + forward + MSE] -> zero_grad ->
+  loss_scaler(backward, grad norm / clip, optimizer step) -> loss read-back + finite check (while the backward runs) -> meters.
 Not reproduced on purpose: the debug block at :74-166 that writes B x 16 x 3 PNGs every step, and in the BB
 variant the bbox rasterisation at :243-249 whose result is never used (the loss weighting is commented out at :294-303).
 """
@@ -30,13 +30,16 @@ def _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_nor
     loss = model.forward_loss(videos, mask, normlize_target) if hasattr(model, "forward_loss") else None
     if loss is None:
         raise TypeError("model must be a mofo_amd PretrainVisionTransformer (optionally wrapped in mofo_amd.dist.DataParallel)")
+    # The reference reads the loss (a device sync) BEFORE it launches the backward (:69 then :172-176), which leaves the
+    # GPU idle for the round trip.  Here backward + grad-norm + AdamW are enqueued first and the loss is read while they
+    # run; a non-finite loss still ends the process at the same place (nothing observes the parameters in between).
+    optimizer.zero_grad()
+    grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False)
     loss_value = loss.item()
     raw.check_status()
     if not math.isfinite(loss_value):
         print("Loss is {}, stopping training".format(loss_value))
         sys.exit(1)
-    optimizer.zero_grad()
-    grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False)
     loss_scale_value = loss_scaler.state_dict()["scale"]
     torch.cuda.synchronize()
     return loss_value, grad_norm, loss_scale_value

@@ -354,7 +354,8 @@ class PretrainRuntime:
         chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
         R = problems[0][0].shape[0]
         tiles = sum(((pr[0].shape[1] + 127) // 128) * ((pr[1].shape[1] + 127) // 128) for pr in problems)
-        splits = 1 if tiles >= 200 else int(max(1, min(-(-400 // tiles), 16, R // 1024)))
+        thr, target = int(os.environ.get("MOFO_WGRAD_THR", "200")), int(os.environ.get("MOFO_WGRAD_TARGET", "400"))
+        splits = 1 if tiles >= thr else int(max(1, min(-(-target // tiles), 16, R // 1024)))
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
