@@ -150,7 +150,9 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
 // lie wholly inside C take a branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of
 // up to 32 VGPRs, the first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
 template <int EPI, int MI, int PASSES>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int m0, int n0, int wm, int wn, int lane) {
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int m0, int n0, int wm, int wn, int lane,
+                                         bool stamp = true) {   // stamp: trace builds only
+    (void)stamp;
     constexpr int WROWS = 16 * MI;              // rows of the wave tile
     constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
     constexpr int BMT = 32 * MI;
@@ -199,7 +201,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                 if (g % NIT == 0) {
                     if (g) __builtin_amdgcn_wave_barrier();
                     stage_acc(g / NIT);
-                    if (g == 0) MOFO_TRACE(3);
+                    if (g == 0 && stamp) MOFO_TRACE(3);
                 }
                 const int r = (g % NIT) * 8 + (lane >> 3);
                 const int m = mb + g * 8 + (lane >> 3);
@@ -234,7 +236,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
         for (int ps = 0; ps < PASSES; ++ps) {
             const int mp = mb + ps * PROWS;
             stage_acc(ps);
-            if (ps == 0) MOFO_TRACE(3);
+            if (ps == 0 && stamp) MOFO_TRACE(3);
             // one 256-B contiguous row segment per atomic wave-instruction (full chip-wide atomic rate)
             const int n = nb + lane;
             if (n < p.N) {
@@ -276,7 +278,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                 if (g % NIT == 0) {
                     if (g) __builtin_amdgcn_wave_barrier();
                     stage_acc(g / NIT);
-                    if (g == 0) MOFO_TRACE(3);
+                    if (g == 0 && stamp) MOFO_TRACE(3);
                 }
                 if (g % CH == 0 && g + CH < NG) load_chunk(g / CH + 1, rr[(g / CH + 1) & 1]);
                 const int r = (g % NIT) * 4 + (lane >> 4);
@@ -485,8 +487,9 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
     __shared__ __attribute__((aligned(16))) unsigned char smem[STG + EP_BYTES];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    MOFO_TRACE(0);
     MOFO_TRACE_ID();
+    int ti = 0;   // tile counter of this block (trace build: the third tile is stamped)
+    (void)ti;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int nk = p.K / BK;
     // XCD-aware order over the virtual grid of `total` one-tile blocks (grid is `total` or a multiple of 8, so a block's
@@ -525,9 +528,10 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ti == 2) MOFO_TRACE(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first k-stage (and the previous epilogue's stores)
         __builtin_amdgcn_s_barrier();
-        MOFO_TRACE(1);
+        if (ti == 2) MOFO_TRACE(1);
         for (int t = 0; t < nk; ++t) {
             bf16x8 af[2][MI], bfr[2][4];
 #pragma unroll
@@ -553,18 +557,18 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
                 __builtin_amdgcn_s_barrier();      // k-stage t+1 landed and is visible to every wave
             }
         }
-        MOFO_TRACE(2);
-        epilogue<EPI, MI, MI>(p, acc, ep, m0, n0, wm, wn, lane);
-        MOFO_TRACE(4);
+        if (ti == 2) MOFO_TRACE(2);
+        epilogue<EPI, MI, MI>(p, acc, ep, m0, n0, wm, wn, lane, ti == 2);
+        if (ti == 2) {
+            MOFO_TRACE(4);
+            MOFO_TRACE(5);
+        }
+        ++ti;
         if (!has_next) break;
         w = wnext;
         m0 = m1;
         n0 = n1;
     }
-#ifdef MOFO_GEMM_TRACE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MOFO_TRACE(5);
-#endif
 }
 
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
