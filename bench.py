@@ -25,6 +25,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 STEP_FLOP_PER_CLIP = 202.3e9   # algorithmic training-step FLOPs per clip (ViT-B, dec 4, mask 0.9)
+ENC_STEP_FLOP_PER_CLIP = 84.37e9  # ... of which the encoder's forward + backward
 PEAK_BF16 = 2.5e15             # MI355X dense bf16 MFMA peak (guides/MI355X_MICROARCH.md)
 PEAK_HBM = 8.0e12              # spec HBM3E bandwidth
 
@@ -76,6 +77,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing (roofline block)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
+    ap.add_argument("--no-encoder-step", action="store_true", help="skip the encoder-only (fwd+bwd) timing reported in config")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -214,6 +216,29 @@ def main():
                 print(f"{names.get(k, '_'.join(str(x) for x in k)):28s} {v['launches'] // max(1, n_instr):8d} {v['ms'] / max(1, n_instr):9.3f} "
                       f"{v['ms'] / wtot:6.1%} {rate / (1e12 if mf else 1e9):9.1f} {'TF/s' if mf else 'GB/s'}  (max {v['max_ms']:.3f} ms)", file=sys.stderr)
             print(f"sum of kernel time {wtot / max(1, n_instr):.3f} ms/step (warm-up) vs timed wall {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)
+
+    # Encoder-only step (SURVEY.md 8d / north star: "roofline fraction of the ViT-B encoder step"): patch gather + tubelet
+    # embed + 12 blocks + norm forward, and the backward of exactly that (dgrad chain + grouped weight gradients incl. the
+    # patch-embed wgrad) from the d(encoder output) buffer the last full step left behind.  84.37 GFLOP per clip.
+    if world == 1 and not force_dp and not args.no_encoder_step:
+        rt = model.runtime()
+        w = next(iter(rt._ws.values()))
+
+        def enc_step():
+            rt.cached(w, "bench_enc_fwd", lambda: rt.encoder_forward(w))
+            rt._accumulate = False
+            rt.cached(w, "bench_enc_bwd", lambda: rt.encoder_backward(w, w.d_encout))
+        for _ in range(3):
+            enc_step()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_enc = 20
+        for _ in range(n_enc):
+            enc_step()
+        torch.cuda.synchronize()
+        enc_ms = 1e3 * (time.perf_counter() - t1) / n_enc
+        out["config"]["encoder_step"] = {"ms": round(enc_ms, 3), "clips_per_s": round(B / enc_ms * 1e3, 1),
+                                         "mfma_frac": round(B / (enc_ms * 1e-3) * ENC_STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

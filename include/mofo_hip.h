@@ -130,6 +130,20 @@ int mofo_target_mse(const float* clips, int B, int C, int T, int H, int W, int p
                     const int* msk_idx, int n_msk, const void* pred, int ldp, int normalize, float grad_scale,
                     float* row_loss, float* loss, void* dpred, int lddp, void* target_out_f32, void* stream);
 
+/* ---- "next" rows, same boundary rules.
+ * Reconstruction video of the inference / visualisation script, run_videomae_vis.py:150-180: every token standardised per
+ * channel over its 512 pixels (unbiased variance, 1e-6 after the sqrt), masked tokens replaced by the model's predictions
+ * (pred [B*n_msk, 1536], bf16 or f32, rows in the order of msk_idx), multiplied back by the token's own std and mean.
+ * rec / masked / ori: f32 [B,3,T,H,W] in [0,1] pixel units; masked (rec on visible tokens, 0 on masked ones) and ori
+ * (clips * std + mean) may be NULL.  msk_idx: ascending per clip, as mofo_mask_to_indices writes it. ---- */
+int mofo_reconstruct(const float* clips, int B, int C, int T, int H, int W, int pt, int p, const int* msk_idx, int n_msk,
+                     const void* pred, int pred_is_bf16, int ldp, float* rec, float* masked, float* ori, void* stream);
+/* Token mean pooling + fc_norm of the fine-tune / feature-extraction model, modeling_finetune.py:403-405
+ * (`self.fc_norm(x.mean(1))`): x f32 [B*N, D] -> out_f32 [B, D] (+ bf16 copy for the head GEMM, may be NULL).
+ * pooled_ws: f32 [B, D] scratch (zeroed by the call). ---- */
+int mofo_token_mean_norm(const float* x, int ldx, int B, int N, int D, const float* w, const float* b, float eps,
+                         float* pooled_ws, float* out_f32, void* out_bf16, void* stream);
+
 /* ---- optimizer side on FLAT buffers: utils.py:376-388 (global grad L2 norm), torch.nn.utils.clip_grad_norm_
  * (utils.py:359), torch.optim.AdamW as configured by optim_factory.py:91-127 (two param groups: decayed / not decayed).
  * n is a multiple of 1024; chunk c covers elements [1024c, 1024c+1024); chunk_group[c] (0/1) selects (lr0,wd0) or

@@ -208,6 +208,49 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     if (part == 0 && c < D && b0 < b1) atomicAdd((which ? db : dw) + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
+// Mean pooling over a clip's tokens + fc_norm of the fine-tune / feature-extraction model (modeling_finetune.py:403-405:
+// `self.fc_norm(x.mean(1))`).  Stage 1: every block adds 32 token rows of one clip into pooled[b, :] (f32 atomics: B*D
+// addresses, N/32 adds each).  Stage 2: one block per clip scales by 1/N and applies LayerNorm; writes f32 and bf16.
+__global__ __launch_bounds__(256) void token_sum_kernel(const float* __restrict__ x, int ldx, int N, int D, float* __restrict__ pooled) {
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * 32, r1 = min(N, r0 + 32);
+    for (int c = threadIdx.x * 4; c < D; c += 1024) {
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        for (int r = r0; r < r1; ++r) a += *(const f32x4*)(x + ((size_t)b * N + r) * ldx + c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) atomicAdd(pooled + (size_t)b * D + c + k, a[k]);
+    }
+}
+
+__global__ __launch_bounds__(256) void pool_norm_kernel(const float* __restrict__ pooled, int N, int D, const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float eps, float* __restrict__ out_f32,
+                                                        bf16_t* __restrict__ out_bf16) {
+    __shared__ float red[8];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float inv_n = 1.0f / (float)N;
+    auto block_sum = [&](float v) {
+        v = wave_sum(v);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    float s = 0.f;
+    for (int c = tid; c < D; c += 256) s += pooled[(size_t)b * D + c] * inv_n;
+    const float mu = block_sum(s) / (float)D;
+    float ss = 0.f;
+    for (int c = tid; c < D; c += 256) {
+        const float d = pooled[(size_t)b * D + c] * inv_n - mu;
+        ss += d * d;
+    }
+    const float rstd = rsqrtf(block_sum(ss) / (float)D + eps);
+    for (int c = tid; c < D; c += 256) {
+        const float y = (pooled[(size_t)b * D + c] * inv_n - mu) * rstd * w[c] + bias[c];
+        out_f32[(size_t)b * D + c] = y;
+        if (out_bf16) out_bf16[(size_t)b * D + c] = f32_to_bf16(y);
+    }
+}
+
 }  // namespace
 
 static int ln_check(const char* who, int M, int D, int rows_in, int rows_out) {
@@ -261,5 +304,18 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
         hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(ceil_div(D, 64), 2, FIN_SLICES), dim3(256), 0, s, (const float*)partial_ws, blocks, D, dw, db);
         MOFO_CHECK_LAUNCH("mofo_layernorm_bwd(finalize)");
     }
+    return MOFO_OK;
+}
+
+extern "C" int mofo_token_mean_norm(const float* x, int ldx, int B, int N, int D, const float* w, const float* b, float eps,
+                                    float* pooled_ws, float* out_f32, void* out_bf16, void* stream) {
+    if (!x || !w || !b || !pooled_ws || !out_f32) MOFO_FAIL(MOFO_EINVAL, "mofo_token_mean_norm: null pointer");
+    if (B <= 0 || N <= 0 || D <= 0 || D % 4 || ldx % 4 || ldx < D) MOFO_FAIL(MOFO_EINVAL, "mofo_token_mean_norm: bad sizes (D, ldx multiples of 4)");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(pooled_ws, 0, (size_t)B * D * sizeof(float), s) != hipSuccess) MOFO_FAIL(MOFO_ERUNTIME, "mofo_token_mean_norm: memset failed");
+    hipLaunchKernelGGL(token_sum_kernel, dim3(ceil_div(N, 32), B), dim3(256), 0, s, x, ldx, N, D, pooled_ws);
+    MOFO_CHECK_LAUNCH("mofo_token_mean_norm(sum)");
+    hipLaunchKernelGGL(pool_norm_kernel, dim3(B), dim3(256), 0, s, (const float*)pooled_ws, N, D, w, b, eps, out_f32, (bf16_t*)out_bf16);
+    MOFO_CHECK_LAUNCH("mofo_token_mean_norm(norm)");
     return MOFO_OK;
 }

@@ -123,6 +123,112 @@ __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restri
     }
 }
 
+// Reconstruction video of the inference / visualisation path (run_videomae_vis.py:150-180): one wave per token (ALL tokens).
+// Every token is standardised per channel over its 512 pixels exactly like the training target; masked tokens take the
+// model's prediction instead, and everything is multiplied back by the token's own (std + 1e-6) and mean:
+//   rec = (masked ? pred : (u - mu) / sd) * sd + mu,   u = x * imagenet_std + imagenet_mean,   sd = sqrt(var_unbiased) + 1e-6
+// `masked_out` = rec on visible tokens, 0 on masked ones (:163-167,180); `ori_out` = u (:152).  The masked tokens of a clip
+// are given as the ascending index list the training path already builds; a token finds its prediction row by bisection.
+template <bool PRED_BF16>
+__global__ __launch_bounds__(256) void reconstruct_kernel(const float* __restrict__ clips, int T, int H, int W, int N,
+                                                          const int* __restrict__ msk_idx, int n_msk, int rows,
+                                                          const void* __restrict__ pred, int ldp,
+                                                          float* __restrict__ rec_out, float* __restrict__ masked_out,
+                                                          float* __restrict__ ori_out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / N, tok = row - b * N;
+    // bisection in msk_idx[b, :] (wave-uniform)
+    int lo = 0, hi = n_msk;
+    const int* mi = msk_idx + (size_t)b * n_msk;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (mi[mid] < tok) lo = mid + 1;
+        else hi = mid;
+    }
+    const bool is_masked = lo < n_msk && mi[lo] == tok;
+    const size_t prow = (size_t)b * n_msk + lo;
+    const int gw = W >> 4, gh = H >> 4;
+    const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
+    const size_t cb = (size_t)b * 3 * T * H * W;
+
+    float u[3][2][4];
+    size_t off[3][2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int e = q * 64 + lane;
+            const int seg = e >> 2, qq = e & 3;
+            const int p0 = seg >> 4, p1 = seg & 15;
+            off[c][q] = cb + (((size_t)c * T + (tt * 2 + p0)) * H + (th * 16 + p1)) * W + tw * 16 + qq * 4;
+            const f32x4 v = *(const f32x4*)(clips + off[c][q]);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) u[c][q][k] = v[k] * c_std[c] + c_mean[c];
+        }
+    }
+    float mu[3], sd[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += u[c][q][k];
+        mu[c] = wave_sum(s) * (1.0f / 512.0f);
+        float ss = 0.f;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = u[c][q][k] - mu[c];
+                ss += d * d;
+            }
+        sd[c] = sqrtf(wave_sum(ss) * (1.0f / 511.0f)) + 1e-6f;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int e = q * 64 + lane;
+        float pv[12];
+        if (is_masked) {
+            if constexpr (PRED_BF16) {
+                const bf16_t* pp = (const bf16_t*)pred + prow * ldp + e * 12;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const u32x2 w = *(const u32x2*)(pp + 4 * i);
+                    pv[4 * i + 0] = bf16lo_to_f32(w[0]);
+                    pv[4 * i + 1] = bf16hi_to_f32(w[0]);
+                    pv[4 * i + 2] = bf16lo_to_f32(w[1]);
+                    pv[4 * i + 3] = bf16hi_to_f32(w[1]);
+                }
+            } else {
+                const float* pp = (const float*)pred + prow * ldp + e * 12;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const f32x4 w = *(const f32x4*)(pp + 4 * i);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) pv[4 * i + k] = w[k];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            f32x4 r, m, o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float z = is_masked ? pv[k * 3 + c] : (u[c][q][k] - mu[c]) / sd[c];
+                r[k] = z * sd[c] + mu[c];
+                m[k] = is_masked ? 0.f : r[k];
+                o[k] = u[c][q][k];
+            }
+            *(f32x4*)(rec_out + off[c][q]) = r;
+            if (masked_out) *(f32x4*)(masked_out + off[c][q]) = m;
+            if (ori_out) *(f32x4*)(ori_out + off[c][q]) = o;
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int mofo_target_mse(const float* clips, int B, int C, int T, int H, int W, int pt, int p, const int* msk_idx,
@@ -141,5 +247,22 @@ extern "C" int mofo_target_mse(const float* clips, int B, int C, int T, int H, i
     MOFO_CHECK_LAUNCH("mofo_target_mse");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, rows, 1.0 / numel, loss);
     MOFO_CHECK_LAUNCH("mofo_target_mse(reduce)");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_reconstruct(const float* clips, int B, int C, int T, int H, int W, int pt, int p, const int* msk_idx, int n_msk,
+                                const void* pred, int pred_is_bf16, int ldp, float* rec, float* masked, float* ori, void* stream) {
+    if (!clips || !rec || (n_msk > 0 && (!msk_idx || !pred))) MOFO_FAIL(MOFO_EINVAL, "mofo_reconstruct: null pointer");
+    if (C != 3 || pt != 2 || p != 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_reconstruct: built for 3 channels, tubelet 2, patch 16 (got %d,%d,%d)", C, pt, p);
+    if (B <= 0 || n_msk < 0 || T % 2 || H % 16 || W % 16 || (n_msk > 0 && (ldp % 4 || ldp < 1536))) MOFO_FAIL(MOFO_EINVAL, "mofo_reconstruct: bad sizes");
+    const int N = (T / 2) * (H / 16) * (W / 16);
+    if (n_msk > N) MOFO_FAIL(MOFO_EINVAL, "mofo_reconstruct: n_msk %d > tokens %d", n_msk, N);
+    const int rows = B * N;
+    hipStream_t s = (hipStream_t)stream;
+    if (pred_is_bf16)
+        hipLaunchKernelGGL(reconstruct_kernel<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, clips, T, H, W, N, msk_idx, n_msk, rows, pred, ldp, rec, masked, ori);
+    else
+        hipLaunchKernelGGL(reconstruct_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, clips, T, H, W, N, msk_idx, n_msk, rows, pred, ldp, rec, masked, ori);
+    MOFO_CHECK_LAUNCH("mofo_reconstruct");
     return MOFO_OK;
 }

@@ -363,6 +363,39 @@ def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, los
     return loss
 
 
+def reconstruct(clips, pt, p, msk_idx, pred, rec, masked=None, ori=None):
+    """run_videomae_vis.py:150-180 (see include/mofo_hip.h): pred bf16 or f32 [B*n_msk, 1536]"""
+    _chk(clips, F32, "clips", 5), _chk(msk_idx, I32, "msk_idx", 2), _chk(rec, F32, "rec", 5)
+    B, Cc, T, H, W = clips.shape
+    n_msk = msk_idx.shape[1]
+    L = Cc * pt * p * p
+    if pred.dtype not in (BF16, F32) or pred.dim() != 2 or pred.shape != (B * n_msk, L) or pred.device != clips.device:
+        raise ValueError("reconstruct: pred must be bf16/f32 [B*n_msk, C*pt*p*p] on the clips' device")
+    if not clips.is_contiguous() or not msk_idx.is_contiguous() or msk_idx.shape[0] != B:
+        raise ValueError("reconstruct: shape mismatch")
+    for t, nm in ((rec, "rec"), (masked, "masked"), (ori, "ori")):
+        if t is not None and (t.dtype != F32 or t.shape != clips.shape or not t.is_contiguous() or t.device != clips.device):
+            raise ValueError(f"reconstruct: {nm} must be a contiguous f32 tensor shaped like clips")
+    nout = 1 + (masked is not None) + (ori is not None)
+    _run("mofo_reconstruct", ("reconstruct",), 4.0 * clips.numel() * (1 + nout) + pred.numel() * pred.element_size(), _p(clips), B, Cc, T, H, W,
+         pt, p, _p(msk_idx), n_msk, _p(pred), 1 if pred.dtype == BF16 else 0, _ld(pred), _p(rec), _p(masked), _p(ori))
+    return rec
+
+
+def token_mean_norm(x, B, N, w, b, eps, pooled_ws, out_f32, out_bf16=None):
+    """modeling_finetune.py:403-405: fc_norm(x.mean(1)) over x f32 [B*N, D]"""
+    _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(pooled_ws, F32, "pooled_ws"), _chk(out_f32, F32, "out_f32", 2)
+    D = x.shape[1]
+    if x.shape[0] != B * N or w.numel() != D or b.numel() != D or pooled_ws.numel() < B * D or out_f32.shape != (B, D) or not out_f32.is_contiguous():
+        raise ValueError("token_mean_norm: shape mismatch")
+    if out_bf16 is not None:
+        _chk(out_bf16, BF16, "out_bf16", 2)
+        if out_bf16.shape != (B, D) or not out_bf16.is_contiguous():
+            raise ValueError("token_mean_norm: out_bf16 shape")
+    _run("mofo_token_mean_norm", ("token_mean_norm",), 4.0 * x.numel(), _p(x), _ld(x), B, N, D, _p(w), _p(b), eps, _p(pooled_ws), _p(out_f32), _p(out_bf16))
+    return out_f32
+
+
 def sumsq_norm(g, partial, out_norm):
     _chk(g, F32, "g", 1), _chk(partial, F32, "partial", 1), _chk(out_norm, F32, "out_norm")
     if partial.numel() < 1024:

@@ -211,7 +211,7 @@ class PretrainRuntime:
     """Forward / backward of encoder, bridge (encoder_to_decoder + token assembly), decoder and the fused loss."""
 
     def __init__(self, dims: Dims, store: FlatStore, enc_prefix: Optional[str] = "encoder.", dec_prefix: Optional[str] = "decoder.",
-                 top: bool = True):
+                 top: bool = True, forward_only: bool = False):
         self.d = dims
         self.store = store
         self.dev = store.device
@@ -225,7 +225,8 @@ class PretrainRuntime:
         if dec_prefix is not None:
             self.decW = [self._block_weights(f"{dec_prefix}blocks.{i}.") for i in range(dims.dec_depth)]
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
-        self.segments = self.plan_segments()
+        # forward_only: the fine-tune / feature-extraction forward (modeling_finetune.py) -- no gradient buckets to plan
+        self.segments = [] if forward_only else self.plan_segments()
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None

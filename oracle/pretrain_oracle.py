@@ -347,6 +347,78 @@ def build_targets(x: torch.Tensor, mask: torch.Tensor, cfg: OracleConfig, normal
     return u[mask].reshape(B, -1, u.shape[-1])
 
 
+def reconstruct_video(x: torch.Tensor, mask: torch.Tensor, outputs: torch.Tensor, cfg: OracleConfig):
+    """run_videomae_vis.py:150-176: (ori_img, rec_img, img_mask), each [B,3,T,H,W] in [0,1] pixel units.
+    ori = x*std+mean (:152); every token standardised per channel over its 512 pixels (unbiased variance, 1e-6 after the
+    sqrt, :158-159); masked tokens replaced by the model's predictions (:161); multiplied back by that token's own
+    (std+1e-6) and mean (:172) -- so visible tokens come back as the original pixels up to rounding and masked ones as
+    de-standardised predictions; img_mask = rec * (1 on visible tokens, 0 on masked) (:163-167,180).  The .clamp(0, 0.996)
+    of :174 belongs to the JPEG writer, not to this arithmetic."""
+    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype)[None, :, None, None, None]
+    std = torch.tensor(IMAGENET_STD, dtype=x.dtype)[None, :, None, None, None]
+    ori = x * std + mean
+    B, C, T, H, W = ori.shape
+    pt, p = cfg.tubelet, cfg.patch_size
+    gt, gh, gw = T // pt, H // p, W // p
+    sq = ori.reshape(B, C, gt, pt, gh, p, gw, p).permute(0, 2, 4, 6, 3, 5, 7, 1).reshape(B, gt * gh * gw, pt * p * p, C)
+    mu = sq.mean(dim=-2, keepdim=True)
+    sd = (((sq - mu) ** 2).sum(dim=-2, keepdim=True) / (sq.shape[-2] - 1)).sqrt() + 1e-6
+    patch = ((sq - mu) / sd).reshape(B, gt * gh * gw, -1).clone()
+    patch[mask] = outputs.reshape(-1, patch.shape[-1]).to(patch.dtype)
+    keep = torch.ones_like(patch)
+    keep[mask] = 0
+
+    def unpatch(t):   # 'b (t h w) (p0 p1 p2) c -> b c (t p0) (h p1) (w p2)'
+        t = t.reshape(B, gt, gh, gw, pt, p, p, C).permute(0, 7, 1, 4, 2, 5, 3, 6)
+        return t.reshape(B, C, T, H, W)
+    rec = unpatch(patch.reshape(B, -1, pt * p * p, C) * sd + mu)
+    return ori, rec, rec * unpatch(keep.reshape(B, -1, pt * p * p, C))
+
+
+# --------------------------------------------------------------------------- fine-tune model forward (next row, SURVEY 8f-4)
+def finetune_param_shapes(cfg: OracleConfig, num_classes: int) -> Dict[str, Tuple[int, ...]]:
+    """state_dict schema of modeling_finetune.VisionTransformer with use_mean_pooling=True, init_values=0
+    (modeling_finetune.py:328-352): the pretraining encoder's keys without the ``encoder.`` prefix, ``norm`` is
+    Identity (no parameters), plus fc_norm and head."""
+    s: Dict[str, Tuple[int, ...]] = {}
+    for k, v in param_shapes(cfg).items():
+        if k.startswith("encoder.") and not k.startswith("encoder.norm."):
+            s[k[len("encoder."):]] = v
+    s["fc_norm.weight"] = (cfg.enc_dim,)
+    s["fc_norm.bias"] = (cfg.enc_dim,)
+    s["head.weight"] = (num_classes, cfg.enc_dim)
+    s["head.bias"] = (num_classes,)
+    return s
+
+
+def finetune_keyed_params(cfg: OracleConfig, num_classes: int) -> Dict[str, torch.Tensor]:
+    """xavier-scale name-keyed weights (as keyed_params mode 'xavier') for the fine-tune model"""
+    out: Dict[str, torch.Tensor] = {}
+    for name, shape in finetune_param_shapes(cfg, num_classes).items():
+        n = keyed_normal("ft." + name, shape)
+        if name.endswith(("norm1.weight", "norm2.weight", "norm.weight")):
+            v = 1.0 + 0.1 * n
+        elif len(shape) == 2:
+            v = n * math.sqrt(2.0 / (shape[0] + shape[1]))
+        elif len(shape) == 5:
+            v = n / math.sqrt(shape[1] * shape[2] * shape[3] * shape[4])
+        else:
+            v = 0.02 * n
+        out[name] = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32))
+    return out
+
+
+def finetune_forward(x: torch.Tensor, P: Dict[str, torch.Tensor], cfg: OracleConfig, features_only: bool = False) -> torch.Tensor:
+    """modeling_finetune.py:389-409: patch embed over ALL tokens + sincos pos -> blocks -> (norm = Identity) ->
+    fc_norm(mean over tokens) -> head."""
+    w = P["patch_embed.proj.weight"].reshape(cfg.enc_dim, -1)
+    t = _linear(patchify_tubelets(x, cfg), w, P["patch_embed.proj.bias"]) + sincos_table(cfg.num_patches, cfg.enc_dim)
+    for i in range(cfg.enc_depth):
+        t = block(t, P, f"blocks.{i}.", cfg.enc_heads, cfg.ln_eps)
+    f = _layernorm(t.mean(dim=1), P["fc_norm.weight"], P["fc_norm.bias"], cfg.ln_eps)
+    return f if features_only else _linear(f, P["head.weight"], P["head.bias"])
+
+
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """nn.MSELoss() (engine_for_pretraining.py:27,67): mean over every element."""
     d = pred - target

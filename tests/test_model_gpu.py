@@ -354,3 +354,102 @@ def test_vit_large_32_frames_parity(dev):
     g = {n: p.grad for n, p in model.named_parameters()}
     for n in ("encoder.patch_embed.proj.weight", "encoder.blocks.0.attn.qkv.weight", "decoder.blocks.0.mlp.fc2.weight", "mask_token"):
         assert _rel(g[n], grads[n]) < 6e-2, n
+
+
+# ----------------------------------------------------------------------------- "next" rows
+def _tiny(mode, dev):
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    model, P = _build(cfg, mode, dev)
+    x = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool()
+    return cfg, model, P, x, mask
+
+
+def _vis_case():
+    from oracle import pretrain_oracle as O
+    g = np.load(os.path.join(G, "vis.npz"))
+    cfg = O.VIT_B
+    img = O.keyed_clips(1, cfg, base_seed=2000)
+    mask = torch.from_numpy(g["mask"])[None].bool()
+    outputs = torch.from_numpy(np.random.RandomState(77).standard_normal((1, int(mask.sum()), cfg.patch_dim)).astype(np.float32))
+    return g, cfg, img, mask, outputs
+
+
+@pytest.mark.parametrize("pred_dtype", [torch.float32, torch.bfloat16])
+def test_reconstruct_kernel_matches_reference_fixture(dev, pred_dtype):
+    """mofo_reconstruct against the fixture produced by executing run_videomae_vis.py:150-180 (f32 predictions), and against
+    the oracle on bf16-rounded predictions (what the model hands over)"""
+    from mofo_amd import ops
+    from oracle import pretrain_oracle as O
+    g, cfg, img, mask, outputs = _vis_case()
+    pred = outputs.to(pred_dtype)
+    msk_idx = torch.nonzero(mask[0]).reshape(1, -1).to(torch.int32).to(dev)
+    clips = img.to(dev)
+    rec, masked, ori = (torch.full_like(clips, float("nan")) for _ in range(3))
+    ops.reconstruct(clips, cfg.tubelet, cfg.patch_size, msk_idx, pred.reshape(-1, cfg.patch_dim).to(dev), rec, masked=masked, ori=ori)
+    torch.cuda.synchronize()
+    want = dict(zip(("ori_img", "rec_img", "img_mask"), O.reconstruct_video(img, mask, pred.float(), cfg)))
+    for name, t in (("ori_img", ori), ("rec_img", rec), ("img_mask", masked)):
+        t = t.cpu()
+        assert torch.isfinite(t).all(), name
+        np.testing.assert_allclose(t.numpy(), want[name].numpy(), rtol=1e-5, atol=2e-6)
+        if pred_dtype == torch.float32:
+            np.testing.assert_allclose(t[0, :, :2, :48, :48].numpy(), g[name + "_head"], rtol=1e-5, atol=2e-6)
+            np.testing.assert_allclose(t[0, :, -2:, -48:, -48:].numpy(), g[name + "_tail"], rtol=1e-5, atol=2e-6)
+            assert t.double().sum().item() == pytest.approx(float(g[name + "_sum"]), rel=1e-6)
+            np.testing.assert_allclose(t.double().sum(dim=(0, 1, 3, 4)).numpy(), g[name + "_framesum"], rtol=1e-6)
+
+
+def test_reconstruct_from_model_tiny(dev):
+    """run_videomae_vis.reconstruct(): model forward + reconstruction video vs the oracle model + oracle reconstruction"""
+    from mofo_amd.run_videomae_vis import reconstruct
+    from oracle import pretrain_oracle as O
+    cfg, m, P, x, mask = _tiny("xavier", dev)
+    out = reconstruct(m, x.to(dev), mask.to(dev))
+    with torch.no_grad():
+        pred = O.model_forward(x, mask, P, cfg)
+    ori, rec, masked = O.reconstruct_video(x, mask, pred, cfg)
+    np.testing.assert_allclose(out["ori_img"].cpu().numpy(), ori.numpy(), rtol=1e-5, atol=2e-6)
+    assert _rel(out["rec_img"], rec) < 2e-2
+    assert _rel(out["mask_img"], masked) < 1e-5       # visible tokens only: independent of the predictions
+    vis = masked != 0
+    assert torch.allclose(out["rec_img"].cpu()[vis], ori[vis], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,ncls,nb", [("tiny", 10, 2), ("vitb", 400, 1)])
+def test_finetune_forward_matches_reference_fixture(dev, tag, ncls, nb):
+    """modeling_finetune.VisionTransformer forward (all 1568 tokens, mean pooling, fc_norm, head) vs the fixture produced by
+    the reference model on the same name-keyed weights and clips"""
+    from functools import partial
+    from mofo_amd import modeling_finetune as ft
+    from oracle import pretrain_oracle as O
+    g = np.load(os.path.join(G, f"finetune_{tag}.npz"))
+    cfg = O.TINY if tag == "tiny" else O.VIT_B
+    m = ft.VisionTransformer(img_size=cfg.img_size, patch_size=16, num_classes=ncls, embed_dim=cfg.enc_dim, depth=cfg.enc_depth,
+                             num_heads=cfg.enc_heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6),
+                             all_frames=cfg.num_frames, tubelet_size=2, init_scale=1.0)
+    P = O.finetune_keyed_params(cfg, ncls)
+    assert list(m.state_dict().keys()) == list(P.keys())
+    m.load_state_dict(P, strict=True)
+    m.to(dev).eval()
+    x = O.keyed_clips(nb, cfg, base_seed=3000).to(dev)
+    feat, logits = m.forward_features(x), m(x)
+    assert feat.shape == (nb, cfg.enc_dim) and logits.shape == (nb, ncls) and not logits.requires_grad
+    assert _rel(feat, torch.from_numpy(g["features"])) < 2e-2
+    assert _rel(logits, torch.from_numpy(g["logits"])) < 2e-2
+    assert (logits.argmax(1).cpu() == torch.from_numpy(g["logits"]).argmax(1)).all()
+    # a second call replays the recorded launch list and gives the same bits
+    assert torch.equal(m(x), logits)
+
+
+def test_finetune_loads_pretraining_checkpoint(dev):
+    """run_class_finetuning.py:362-411: encoder.* keys of a pretraining state_dict land in the fine-tune model"""
+    from functools import partial
+    from mofo_amd import modeling_finetune as ft
+    cfg, m, P, x, mask = _tiny("small", dev)
+    f = ft.VisionTransformer(img_size=cfg.img_size, patch_size=16, num_classes=16, embed_dim=cfg.enc_dim, depth=cfg.enc_depth,
+                             num_heads=cfg.enc_heads, mlp_ratio=4, qkv_bias=True, norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    r = f.load_pretrained_encoder(m.state_dict())
+    assert sorted(r.missing_keys) == ["fc_norm.bias", "fc_norm.weight", "head.bias", "head.weight"] and not r.unexpected_keys
+    assert torch.equal(f.state_dict()["blocks.1.mlp.fc2.weight"].cpu(), P["encoder.blocks.1.mlp.fc2.weight"])

@@ -170,3 +170,43 @@ def test_vitb_bb_masks_parity():
         loss = O.mse_loss(out, O.build_targets(x, mask, cfg))
     np.testing.assert_allclose(out[:, :6, :48].numpy(), g["out_slice"], rtol=1e-3, atol=1e-5)
     assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
+
+
+# ----------------------------------------------------------------------------- "next" rows
+def _vis_inputs():
+    g = _load("vis.npz")
+    cfg = O.VIT_B
+    img = O.keyed_clips(1, cfg, base_seed=2000)
+    np.random.seed(10)
+    m = O.tube_mask(cfg.grid, 0.9)
+    assert np.array_equal(m, g["mask"])
+    mask = torch.from_numpy(m)[None].bool()
+    outputs = torch.from_numpy(np.random.RandomState(77).standard_normal((1, int(mask.sum()), cfg.patch_dim)).astype(np.float32))
+    return g, cfg, img, mask, outputs
+
+
+def test_reconstruct_video_matches_reference_vis_arithmetic():
+    g, cfg, img, mask, outputs = _vis_inputs()
+    ori, rec, masked = O.reconstruct_video(img, mask, outputs, cfg)
+    for name, t in (("ori_img", ori), ("rec_img", rec), ("img_mask", masked)):
+        np.testing.assert_allclose(t[0, :, :2, :48, :48].numpy(), g[name + "_head"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_allclose(t[0, :, -2:, -48:, -48:].numpy(), g[name + "_tail"], rtol=1e-5, atol=1e-6)
+        assert t.double().sum().item() == pytest.approx(float(g[name + "_sum"]), rel=1e-6)
+        assert (t.double() ** 2).sum().item() == pytest.approx(float(g[name + "_sqsum"]), rel=1e-6)
+        np.testing.assert_allclose(t.double().sum(dim=(0, 1, 3, 4)).numpy(), g[name + "_framesum"], rtol=1e-6)
+    # visible tokens come back as the original pixels, masked ones are zero in the masked video
+    keep = (masked != 0)
+    assert torch.allclose(rec[keep], ori[keep], atol=1e-5)
+
+
+@pytest.mark.parametrize("tag,ncls,nb", [("tiny", 10, 2), ("vitb", 400, 1)])
+def test_finetune_forward_matches_reference(tag, ncls, nb):
+    g = _load(f"finetune_{tag}.npz")
+    cfg = O.TINY if tag == "tiny" else O.VIT_B
+    P = O.finetune_keyed_params(cfg, ncls)
+    x = O.keyed_clips(nb, cfg, base_seed=3000)
+    with torch.no_grad():
+        feat = O.finetune_forward(x, P, cfg, features_only=True)
+        logits = O.finetune_forward(x, P, cfg)
+    np.testing.assert_allclose(feat.numpy(), g["features"], rtol=2e-4, atol=2e-5)
+    np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-5)

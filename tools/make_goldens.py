@@ -120,6 +120,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-vitb", action="store_true")
+    ap.add_argument("--only-next", action="store_true", help="only the fixtures of the SURVEY 8f 'next' rows (vis.npz, finetune_*.npz)")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -133,6 +134,10 @@ def main():
     import utils as ref_utils
     import engine_for_pretraining as ref_eng
     from oracle import pretrain_oracle as O
+
+    if args.only_next:
+        make_next(args, ref_mg, ref_mf, O)
+        return
 
     # ------------------------------------------------------------------ F1 masks
     out = {}
@@ -364,6 +369,58 @@ def main():
                         names=np.array(names), grad_stats=gstat, grad_head=ghead,
                         out_slice=out0[:, :6, :48].numpy(), out_sum=np.array(out0.double().sum().item()))
     print("vitb_bb: loss", losses, "gn", norms)
+
+
+def make_next(args, ref_mg, ref_mf, O):
+    """Fixtures of the 'next' rows:
+      * vis.npz: the reconstruction arithmetic of run_videomae_vis.py:150-180.  It is inline in that script's main()
+        (between video decoding and JPEG writing), so the assignment statements of those lines are taken from the file AT
+        GENERATION TIME and executed on seeded inputs; the PIL / file-writing statements are left out.
+      * finetune_tiny.npz / finetune_vitb.npz: modeling_finetune.VisionTransformer forward (features + logits)."""
+    import re
+    import textwrap
+    import einops
+    cfg = O.VIT_B
+    img = O.keyed_clips(1, cfg, base_seed=2000)
+    np.random.seed(10)
+    m = ref_mg.TubeMaskingGenerator(cfg.grid, 0.9)()
+    mask = torch.from_numpy(m)[None].flatten(1).to(torch.bool)
+    outputs = torch.from_numpy(np.random.RandomState(77).standard_normal((1, int(mask.sum()), cfg.patch_dim)).astype(np.float32))
+    lines = open(os.path.join(REF, "run_videomae_vis.py")).read().split("\n")[146:181]
+    keep = [l for l in lines if re.match(r"\s*(mean|std|ori_img|img_squeeze|img_norm|img_patch|mask|rec_img|img_mask)(\[bool_masked_pos\])?\s*=", l)]
+    code = textwrap.dedent("\n".join(keep))
+    print("---- executed reference statements (run_videomae_vis.py:150-180)\n" + code + "\n----")
+    ns = dict(torch=torch, rearrange=einops.rearrange, IMAGENET_DEFAULT_MEAN=(0.485, 0.456, 0.406),
+              IMAGENET_DEFAULT_STD=(0.229, 0.224, 0.225), device="cpu", img=img, outputs=outputs, bool_masked_pos=mask,
+              patch_size=(16, 16))
+    exec(code, ns)
+    fx = {"mask": m}
+    for k in ("ori_img", "rec_img", "img_mask"):
+        t = ns[k]
+        fx[k + "_head"] = t[0, :, :2, :48, :48].numpy()
+        fx[k + "_tail"] = t[0, :, -2:, -48:, -48:].numpy()
+        fx[k + "_sum"] = np.array(t.double().sum().item())
+        fx[k + "_sqsum"] = np.array((t.double() ** 2).sum().item())
+        fx[k + "_framesum"] = t.double().sum(dim=(0, 1, 3, 4)).numpy()
+    np.savez_compressed(os.path.join(args.out, "vis.npz"), **fx)
+    print("vis: rec sum", fx["rec_img_sum"], "masked sum", fx["img_mask_sum"])
+
+    for tag, c, ncls, nb in (("tiny", O.TINY, 10, 2), ("vitb", O.VIT_B, 400, 1)):
+        model = ref_mf.VisionTransformer(img_size=c.img_size, patch_size=c.patch_size, num_classes=ncls, embed_dim=c.enc_dim,
+                                         depth=c.enc_depth, num_heads=c.enc_heads, mlp_ratio=c.mlp_ratio, qkv_bias=True,
+                                         norm_layer=partial(torch.nn.LayerNorm, eps=1e-6), all_frames=c.num_frames,
+                                         tubelet_size=c.tubelet, use_mean_pooling=True, init_scale=1.0)
+        P = O.finetune_keyed_params(c, ncls)
+        r = model.load_state_dict(P, strict=True)
+        assert not r.missing_keys and not r.unexpected_keys
+        assert [k for k, _ in model.named_parameters()] == list(P.keys()), "param order differs from oracle schema"
+        model.eval()
+        x = O.keyed_clips(nb, c, base_seed=3000)
+        with torch.no_grad():
+            feat = model.forward_features(x)
+            logits = model(x)
+        np.savez_compressed(os.path.join(args.out, f"finetune_{tag}.npz"), features=feat.numpy(), logits=logits.numpy())
+        print(f"finetune_{tag}: logits[0,:4]", logits[0, :4].tolist())
 
 
 if __name__ == "__main__":
