@@ -237,6 +237,17 @@ def main():
             enc_step()
         torch.cuda.synchronize()
         enc_ms = 1e3 * (time.perf_counter() - t1) / n_enc
+        if args.breakdown and rank == 0:
+            ep = _lib.EventProfiler()
+            _lib.PROFILER = ep
+            for _ in range(3):
+                enc_step()
+            _lib.PROFILER = None
+            es = ep.summary()
+            print(f"encoder-only step {enc_ms:.3f} ms; per class (one stream, 3 instrumented steps):", file=sys.stderr)
+            for k, v in sorted(es.items(), key=lambda kv: -kv[1]["ms"]):
+                print(f"  {'_'.join(str(x) for x in k):24s} {v['launches'] // 3:5d} {v['ms'] / 3:8.3f} ms", file=sys.stderr)
+            print(f"  sum {sum(v['ms'] for v in es.values()) / 3:.3f} ms", file=sys.stderr)
         out["config"]["encoder_step"] = {"ms": round(enc_ms, 3), "clips_per_s": round(B / enc_ms * 1e3, 1),
                                          "mfma_frac": round(B / (enc_ms * 1e-3) * ENC_STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}
 
