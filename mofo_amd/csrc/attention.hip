@@ -16,6 +16,17 @@
 
 namespace {
 
+// Debug build only (-DMOFO_ATTN_TRACE, tools/attn_trace.py): s_memtime stamps inside key tile 10 of wave 0 of every block.
+#ifdef MOFO_ATTN_TRACE
+__device__ unsigned long long g_attn_trace[1 << 18];
+#define ATTN_STAMP(kt, slot)                                                                       \
+    do {                                                                                           \
+        if ((kt) == 10 && threadIdx.x == 0 && blockIdx.x < (1 << 15)) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define ATTN_STAMP(kt, slot)
+#endif
+
 constexpr int HD = 64;
 constexpr int RS = 128;              // LDS row stride in bytes (no padding)
 constexpr int TILE = 32 * RS;        // one 32-row tile
@@ -174,9 +185,11 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         constexpr bool MASKED = decltype(masked_tag)::value;
         const unsigned char* Kt = smem + (WHOLE ? kt : (kt & 1)) * 2 * TILE;
         const unsigned char* Vt = Kt + TILE;
+        ATTN_STAMP(kt, 0);
         f32x16 s = zero16();
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, ks, lane), qf[ks], s, 0, 0, 0);
+        ATTN_STAMP(kt, 1);
         float p[16];
         if constexpr (MODE == 0) {
             // running max m is kept in RAW score units; p = exp2(c * s - c * m) is one FMA + one v_exp per element
@@ -209,6 +222,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             l += ls;
             m = mn;
             const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+            ATTN_STAMP(kt, 2);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 0, lane), pf0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 0, lane), pf1, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 1, lane), pf0, o1, 0, 0, 0);
@@ -226,16 +240,21 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
                 p[r] = pr * (dp[r] - dl);
             }
             const bf16x8 f0 = pack_frag(p, 0), f1 = pack_frag(p, 1);
+            ATTN_STAMP(kt, 2);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 0, lane), f0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 0, lane), f1, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 1, lane), f0, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 1, lane), f1, o1, 0, 0, 0);
         }
+        ATTN_STAMP(kt, 3);
         if constexpr (!WHOLE) {
             if (kt + 1 < nkt) lwrite((kt + 1) & 1);
+            ATTN_STAMP(kt, 4);
             __syncthreads();
+            ATTN_STAMP(kt, 5);
             if (kt + 2 < nkt) gload(kt + 2);
         }
+        ATTN_STAMP(kt, 6);
     };
     const int nfull = N >> 5;
     for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
@@ -506,3 +525,9 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
     if (rc) return rc;
     return mofo_attention_bwd_dkv(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);
 }
+
+#ifdef MOFO_ATTN_TRACE
+extern "C" int mofo_debug_attn_trace_read(void* dst_host, size_t bytes) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_attn_trace), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
+}
+#endif

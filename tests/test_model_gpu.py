@@ -453,3 +453,27 @@ def test_finetune_loads_pretraining_checkpoint(dev):
     r = f.load_pretrained_encoder(m.state_dict())
     assert sorted(r.missing_keys) == ["fc_norm.bias", "fc_norm.weight", "head.bias", "head.weight"] and not r.unexpected_keys
     assert torch.equal(f.state_dict()["blocks.1.mlp.fc2.weight"].cpu(), P["encoder.blocks.1.mlp.fc2.weight"])
+
+
+def test_bench_json_contract(dev):
+    """bench.py prints ONE JSON line with the driver's keys, the roofline block and (N=1) the encoder-only step"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "3", "--batch", "4", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 3 and out["unit"] == "clips/s" and out["dtype"] == "bf16" and out["vs_baseline"] is None
+    assert out["value"] == pytest.approx(4 / out["ms_per_step"] * 1e3, rel=1e-3)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in out["roofline"], k
+    assert out["roofline"]["frac"] == pytest.approx(out["roofline"]["achieved"] / out["roofline"]["peak"], rel=1e-2)
+    assert "workload" in out["config"] and "encoder_step" in out["config"]
+    assert math.isfinite(out["config"]["final_loss"])

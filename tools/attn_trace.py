@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Phase timeline inside one key tile of the attention forward / dQ kernels (GPU box only; debug tooling).
+
+Build first, in the container:  python tools/attn_trace.py --build   (attention.hip with -DMOFO_ATTN_TRACE)
+Stamps (wave 0 of every block, key tile 10): 0 tile start | 1 S = K Q^T MFMAs issued | 2 softmax / dS VALU done (operands
+packed) | 3 PV (or dQ) MFMAs issued | 4 next tile written to LDS | 5 barrier passed | 6 next-next tile's global loads issued.
+usage: attn_trace.py <fwd|dq> B N H
+"""
+import os, sys, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+OUT = os.path.join(ROOT, "tools", "_trace", "libmofo_attn_trace.so")
+if "--build" in sys.argv:
+    from mofo_amd import build as b
+    b.build()
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    obj = os.path.join(os.path.dirname(OUT), "attn_trace.o")
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DMOFO_ATTN_TRACE", "-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
+    objs = [obj] + [os.path.join(b.HERE, "build", s + ".o") for s in b.SOURCES if s != "attention.hip"]
+    subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
+    print(OUT); sys.exit(0)
+
+import ctypes as C
+import numpy as np
+import torch
+from mofo_amd import _lib
+_lib.LIB_PATH = OUT
+from mofo_amd import ops
+kind, B, N, H = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+dev = torch.device("cuda:0")
+r = lambda *s: (torch.randn(*s, device=dev) * 0.5).to(torch.bfloat16)
+qkv = r(B * N, 3 * H * 64); out = torch.empty(B * N, H * 64, dtype=torch.bfloat16, device=dev); lse = torch.empty(B * H * N, device=dev)
+dout = r(B * N, H * 64); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
+ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)
+ops.attention_delta(out, dout, B, N, H, delta)
+f = (lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)) if kind == "fwd" else (lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv))
+for _ in range(5): f()
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20): f()
+e1.record(); torch.cuda.synchronize()
+us = e0.elapsed_time(e1) / 20 * 1e3
+print(f"{kind} B={B} N={N} H={H}: {us:.1f} us (trace build)")
+lib = _lib.load()
+buf = np.zeros((1 << 15) * 8, dtype=np.uint64)
+lib.mofo_debug_attn_trace_read.argtypes = [C.c_void_p, C.c_size_t]; lib.mofo_debug_attn_trace_read.restype = C.c_int
+assert lib.mofo_debug_attn_trace_read(buf.ctypes.data, buf.nbytes) == 0
+t = buf.reshape(-1, 8)
+t = t[t[:, 0] > 0][:, :7].astype(np.int64)
+d = np.diff(t, axis=1)
+print(f"{len(t)} blocks")
+for i, n in enumerate(["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]):
+    print(f"  {n:40s} mean {d[:, i].mean():7.0f}  p10 {np.percentile(d[:, i], 10):7.0f}  p50 {np.percentile(d[:, i], 50):7.0f}  p90 {np.percentile(d[:, i], 90):7.0f} clk")
+print(f"  tile total mean {(t[:, 6] - t[:, 0]).mean():.0f} clk")
