@@ -150,15 +150,12 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
 // lie wholly inside C take a branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of
 // up to 32 VGPRs, the first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
 template <int EPI, int MI, int PASSES>
-__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int m0, int n0, int wm, int wn, int lane,
-                                         bool stamp = true) {   // stamp: trace builds only
+__device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int mb, int nb, bool full_tile, int lane,
+                                         bool stamp = true) {   // mb, nb: first row / column of the wave's tile; stamp: trace builds only
     (void)stamp;
     constexpr int WROWS = 16 * MI;              // rows of the wave tile
     constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
-    constexpr int BMT = 32 * MI;
-    const int mb = m0 + wm * WROWS, nb = n0 + wn * 64;
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
-    const bool full_tile = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
 
     auto stage_acc = [&](int ps) {
 #pragma unroll
@@ -463,7 +460,8 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     // VAR 0 stages the wave's whole 64x64 f32 tile (16 KiB per wave); VAR 1 has 32 KiB of LDS and stages 32 rows per pass.
     constexpr int PASSES = (VAR == 0) ? 1 : 2;
     static_assert(4 * (16 * MI / PASSES) * 64 * 4 <= (VAR == 0 ? 2 : 1) * STG, "epilogue staging must fit the main-loop LDS");
-    epilogue<EPI, MI, PASSES>(p, acc, (float*)smem + wave * ((16 * MI / PASSES) * 64), m0, n0, wm, wn, lane);
+    epilogue<EPI, MI, PASSES>(p, acc, (float*)smem + wave * ((16 * MI / PASSES) * 64), m0 + wm * (16 * MI), n0 + wn * 64,
+                              (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane);
     MOFO_TRACE(4);
 #ifdef MOFO_GEMM_TRACE
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores acknowledged
@@ -558,7 +556,7 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
             }
         }
         if (ti == 2) MOFO_TRACE(2);
-        epilogue<EPI, MI, MI>(p, acc, ep, m0, n0, wm, wn, lane, ti == 2);
+        epilogue<EPI, MI, MI>(p, acc, ep, m0 + wm * (16 * MI), n0 + wn * 64, (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, ti == 2);
         if (ti == 2) {
             MOFO_TRACE(4);
             MOFO_TRACE(5);
@@ -569,6 +567,110 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
         m0 = m1;
         n0 = n1;
     }
+}
+
+// VAR 3: IN-BLOCK SPLIT-K for the grids that cannot fill the chip (the encoder's N = 768 GEMMs at M = 5120: 480 tiles of
+// 64 x 128 for 256 CUs -> 1.9 four-wave blocks per CU, every wave waiting on its own load->MFMA chain).  512 threads = two
+// groups of four waves; both groups own the SAME 64 x 128 output tile and each walks one half of the reduction with its own
+// LDS stage (the VAR 1 loop; a k-stage past the end reads zeros through the SRD), so a CU holds twice the waves for the
+// same tiles.  The halves meet in LDS: a group hands the partner the 16-row tile it does not own, adds the one it receives,
+// and runs the epilogue of its own 16 rows -- the epilogue is spread over all eight waves too.
+template <int LA, int LB, int EPI>
+__global__ __launch_bounds__(512, 2) void gemm_ksplit_kernel(GemmP p, int total) {
+    static_assert(LA == OPL_ROW, "built for the ROW A operand (NT / NN)");
+    constexpr int MI = 2;
+    constexpr int BMT = 64;
+    constexpr int A_BYTES = BMT * 64 * 2;
+    constexpr int STG = A_BYTES + TILE_BYTES;                    // 24 KiB per group
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = wave >> 2, w4 = wave & 3;
+    const int wm = w4 >> 1, wn = w4 & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int m0, n0;
+    {
+        const int w = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = w & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+        m0 = (wg / tiles_n) * BMT;
+        n0 = (wg % tiles_n) * BN;
+    }
+    const int nk = p.K / BK;
+    const int nkh = (nk + 1) >> 1;                               // k-stages per group (the second group's last may be empty)
+    const int grp_u = __builtin_amdgcn_readfirstlane(grp), w4_u = __builtin_amdgcn_readfirstlane(w4);
+    const int kb = grp_u * nkh * BK;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)((((size_t)p.M - 1) * p.lda + p.K) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)p.B, 0, (int)((LB == OPL_ROW ? ((size_t)p.N - 1) * p.ldb + p.K : ((size_t)p.K - 1) * p.ldb + p.N) * 2), 0x00020000);
+    int va0, va1, vb0, vb1;
+    srd_lane_offsets<LA>(p.lda, lane, va0, va1);
+    srd_lane_offsets<LB>(p.ldb, lane, vb0, vb1);
+    unsigned char* gs = smem + grp_u * STG;
+    // NT: both operands are k-contiguous rows -- a k offset past K inside the LAST row would be in range, so an empty
+    // trailing k-stage is skipped explicitly (nk odd); NN's B rows past K are out of range by themselves.
+    auto stage = [&](int t) {
+        const int k0 = kb + t * BK;
+        if (k0 < p.K) {
+            stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, k0, gs, w4_u);
+            stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, k0, gs + A_BYTES, w4_u);
+        }
+    };
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    stage(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* ta = gs;
+    const unsigned char* tb = gs + A_BYTES;
+    for (int t = 0; t < nkh; ++t) {
+        const bool live = kb + t * BK < p.K;                     // group-uniform
+        bf16x8 af[2][MI], bfr[2][4];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[ks][i] = read_frag<LA>(ta, wm * (16 * MI) + 16 * i, ks, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bfr[ks][i] = read_frag<LB>(tb, wn * 64 + 16 * i, ks, lane);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nkh) stage(t + 1);
+        if (live) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    }
+    // exchange: group g keeps row tile i = g of every wave tile and gives away i = 1 - g (4 f32x4 per lane -> 16 KiB per group)
+    {
+        f32x4* mine = (f32x4*)gs;
+        const f32x4* theirs = (const f32x4*)(smem + (1 - grp_u) * STG);
+        const int slot = w4 * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mine[j * 256 + slot] = grp ? acc[0][j] : acc[1][j];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 o = theirs[j * 256 + slot];
+            if (grp) acc[1][j] += o;
+            else acc[0][j] += o;
+        }
+        __syncthreads();                                         // the exchange area becomes the epilogue staging area
+    }
+    f32x4 own[1][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) own[0][j] = grp ? acc[1][j] : acc[0][j];
+    epilogue<EPI, 1, 1>(p, own, (float*)smem + wave * (16 * 64), m0 + wm * 32 + grp * 16, n0 + wn * 64,
+                        (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false);
 }
 
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
@@ -598,14 +700,24 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         const bool can_persist = g.count == 1 && !p.atomic && p.k_per_split >= p.K && EPI != MOFO_EPI_POS_F32;
         int var = forced >= 0 ? forced : ((EPI == MOFO_EPI_RESID_F32 && total <= 768) || !can_persist ? 0 : 2);
         if (var == 2 && !can_persist) var = 1;
-        if (var == 2) {
+        // grids of at most two 64-row tiles per CU with a reduction worth splitting: in-block split-K (VAR 3)
+        static int ksplit_on = -1;
+        if (ksplit_on < 0) {
+            const char* e = getenv("MOFO_GEMM_KSPLIT");
+            ksplit_on = e ? atoi(e) : 1;
+        }
+        if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && ((forced < 0 && ksplit_on) || forced == 3)) {
+            hipLaunchKernelGGL((gemm_ksplit_kernel<LA, LB, EPI>), dim3(total), dim3(512), 0, s, p, total);
+        } else if (var == 2) {
             const dim3 pgrid(total < 768 ? total : 768);
             if (mi == 2) hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 2>), pgrid, block, 0, s, p, total);
             else hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 4>), pgrid, block, 0, s, p, total);
         } else if (mi == 2) {
+            if (var == 3) var = 1;
             if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 2>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 2>), grid, block, 0, s, g);
         } else {
+            if (var == 3) var = 1;
             if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
         }
