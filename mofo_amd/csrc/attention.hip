@@ -23,8 +23,13 @@ __device__ unsigned long long g_attn_trace[1 << 18];
     do {                                                                                           \
         if ((kt) == 10 && threadIdx.x == 0 && blockIdx.x < (1 << 15)) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
+#define FUSED_STAMP(slot)                                                                          \
+    do {                                                                                           \
+        if (threadIdx.x == 0 && blockIdx.x < (1 << 15)) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
+    } while (0)
 #else
 #define ATTN_STAMP(kt, slot)
+#define FUSED_STAMP(slot)
 #endif
 
 constexpr int HD = 64;
@@ -387,6 +392,199 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
 }
 
+// ------------------------------------------------------------------------------------------------ short sequences: ONE backward kernel
+// N <= 160 (the encoder's visible tokens): delta, dQ, dK and dV of one (clip, head) in ONE block of 5 waves, Q / dO / K
+// tiles resident in LDS (71 KiB -> two blocks per CU, the 384 (clip, head) pairs of B=32 run in one round).  The
+// three-kernel form costs 9 + 16 + 22 us per layer for 10 GFLOP -- launch ramps and two recomputations of S and dP.
+// Here every (query tile i, key tile j) pair is visited once, by wave j, in the key-on-lane orientation of
+// attn_dkv_kernel (S^T, dP^T, P, dS -> dV_j, dK_j in registers: 5 MFMA products instead of 7).  dQ needs dS with the
+// QUERY on the lane and is accumulated by the wave that OWNS the query tile: at step s wave j works on query tile
+// i = (j + s) mod T and leaves dS_ij in its 2 KiB scratch as [key][query] bf16; after a barrier wave i picks up the
+// scratch of wave j = (i - s) mod T through the transposing `ds_read_b64_tr_b16` and adds K_j^T dS_ij to its dQ_i^T
+// registers; a second barrier frees the scratch.  delta = rowsum(dO * O) is computed while the tiles are staged.
+constexpr int FUSED_NW = 5;
+constexpr int SCR = 64;                                        // scratch row stride: 32 queries x bf16
+constexpr int FUSED_SMEM = 3 * FUSED_NW * TILE + FUSED_NW * 256 + FUSED_NW * 32 * SCR;   // 72 960 B
+
+// B operand = TRANSPOSE of a wave's dS scratch [32 keys][32 queries]: lane <-> query, k slots <-> keys in tr_frag's order
+__device__ __forceinline__ bf16x8 tr_frag_scratch(const unsigned char* tile, int s2, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hh = lane >> 5;
+    const int r0 = 16 * s2 + 4 * hh + q, r1 = r0 + 8;
+    const int chunk = 2 * (g & 1) + (pp >> 1), sub = (pp & 1) * 8;
+    const unsigned char* a0 = tile + r0 * SCR + ((chunk ^ (swz(r0) & 3)) << 4) + sub;
+    const unsigned char* a1 = tile + r1 * SCR + ((chunk ^ (swz(r1) & 3)) << 4) + sub;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)LDS_PTR(a1));
+    const u32x2 l2 = __builtin_bit_cast(u32x2, lo), h2 = __builtin_bit_cast(u32x2, hi);
+    const u32x4 r = {l2[0], l2[1], h2[0], h2[1]};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
+__global__ __launch_bounds__(FUSED_NW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int G, int N, int H, float c,
+                                                                          float scale, const bf16_t* __restrict__ out, int ldo,
+                                                                          const bf16_t* __restrict__ dout, int lddo,
+                                                                          const float* __restrict__ lse2, float* __restrict__ delta_out,
+                                                                          bf16_t* __restrict__ dqkv, int lddqkv) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
+    unsigned char* QT = fsm;                                   // [5][TILE]
+    unsigned char* OT = QT + FUSED_NW * TILE;                  // dO tiles
+    unsigned char* KT = OT + FUSED_NW * TILE;
+    float* LD = (float*)(KT + FUSED_NW * TILE);                // [5][64]: 32 lse2 + 32 delta per query tile
+    unsigned char* SC = (unsigned char*)(LD + FUSED_NW * 64);  // [5][32 x SCR] per-wave dS scratch, [key][query]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    int xb, b, h;
+    if (!decode_block(1, G, H, xb, b, h)) return;
+    const int D = H * HD;
+    const bf16_t* base = qkv + (size_t)b * N * ldqkv;
+    const bf16_t* qp = base + h * HD;
+    const bf16_t* kp = base + D + h * HD;
+    const bf16_t* vp = base + 2 * D + h * HD;
+    const bf16_t* dop = dout + (size_t)b * N * lddo + h * HD;
+    const bf16_t* op = out + (size_t)b * N * ldo + h * HD;
+    const float* lp = lse2 + ((size_t)b * H + h) * N;
+    const int nt = (N + 31) >> 5;                              // tiles (<= 5)
+    FUSED_STAMP(0);
+
+    // ---- this wave's V rows as MFMA B fragments (key on the lane); its K fragments are re-read from the LDS tile per step
+    const int ki = wave * 32 + (lane & 31);
+    const int krow = ki < N ? ki : N - 1;
+    const bool kvalid = ki < N;
+    bf16x8 vf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
+    // ---- stage Q, dO, K tiles; lse2 and delta per query row (all loads of all tiles issued before the first is consumed)
+    if (tid < 256) {
+        const int rl = tid >> 3, ch = tid & 7;
+        // two batches (3 + 2 tiles): the loads of a batch are all issued before its first use; 80 staging VGPRs at once
+        // would not fit beside the 3-waves-per-SIMD register budget
+#pragma unroll
+        for (int t0 = 0; t0 < FUSED_NW; t0 += 3) {
+            constexpr int NB = 3;
+            u32x4 q[NB], k[NB];
+            bf16x8 g[NB], o[NB];
+            float lv[NB];
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int t = t0 + u;
+                if (t < nt && t < FUSED_NW) {
+                    const int row = t * 32 + rl;
+                    const int r = row < N ? row : N - 1;
+                    q[u] = *(const u32x4*)(qp + (size_t)r * ldqkv + ch * 8);
+                    k[u] = *(const u32x4*)(kp + (size_t)r * ldqkv + ch * 8);
+                    g[u] = *(const bf16x8*)(dop + (size_t)r * lddo + ch * 8);
+                    o[u] = *(const bf16x8*)(op + (size_t)r * ldo + ch * 8);
+                    lv[u] = lp[r];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < NB; ++u) {
+                const int t = t0 + u;
+                if (t < nt && t < FUSED_NW) {
+                    const int row = t * 32 + rl;
+                    const int off = t * TILE + rl * RS + ((ch ^ swz(rl)) << 4);
+                    *(u32x4*)(QT + off) = q[u];
+                    *(u32x4*)(KT + off) = k[u];
+                    *(bf16x8*)(OT + off) = g[u];
+                    float part = 0.f;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) part += (float)g[u][j] * (float)o[u][j];
+                    part += __shfl_xor(part, 1, 64);
+                    part += __shfl_xor(part, 2, 64);
+                    part += __shfl_xor(part, 4, 64);
+                    if (ch == 0) {
+                        // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
+                        LD[t * 64 + rl] = row < N ? lv[u] : 1.0e30f;
+                        LD[t * 64 + 32 + rl] = row < N ? part : 0.f;
+                        if (row < N && delta_out) delta_out[((size_t)b * H + h) * N + row] = part;
+                    }
+                }
+            }
+        }
+    }
+    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16(), q0 = zero16(), q1 = zero16();
+    FUSED_STAMP(1);
+    __syncthreads();
+    FUSED_STAMP(2);
+
+    const bool active = wave < nt;                             // waves beyond the last tile only keep the barriers company
+    unsigned char* Sw = SC + wave * (32 * SCR);
+    const unsigned char* Kw = KT + wave * TILE;
+    for (int st = 0; st < nt; ++st) {
+        if (active) {
+            int qt = wave + st;
+            qt = qt >= nt ? qt - nt : qt;
+            const unsigned char* Qt = QT + qt * TILE;
+            const unsigned char* Ot = OT + qt * TILE;
+            const float* Lt = LD + qt * 64;
+            const float* Dt = Lt + 32;
+            f32x16 s = zero16(), dpv = zero16();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), row_frag(Kw, ks, lane), s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
+            float p[16], ds[16];
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+                const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    const float pr = fast_exp2(s[r] * c - lv[e]);
+                    p[r] = pr;
+                    ds[r] = pr * (dpv[r] - dv[e]);
+                }
+            }
+            const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+            const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
+            // dS tile to the scratch as [key = lane & 31][query]: registers 4 rg .. 4 rg + 3 are queries 8 rg + 4 hh .. + 3;
+            // a key beyond N must not reach dQ (its P is not masked in this orientation)
+            {
+                const int kr = lane & 31;
+                const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
+                const u32x2 z = {0u, 0u};
+                const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
+                                    kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
+            }
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 0, lane), pf0, dv0, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 0, lane), pf1, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 1, lane), pf0, dv1, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 1, lane), pf1, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 0, lane), sf0, dk0, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
+        }
+        if (st == 0) FUSED_STAMP(3);
+        __syncthreads();                                       // every wave's dS of this step is in its scratch
+        if (st == 0) FUSED_STAMP(4);
+        if (active) {
+            // dQ_wave^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query],  j = the wave that worked on this query tile
+            int j = wave - st;
+            j = j < 0 ? j + nt : j;
+            const unsigned char* Sj = SC + j * (32 * SCR);
+            const unsigned char* Kj = KT + j * TILE;
+            const bf16x8 t0 = tr_frag_scratch(Sj, 0, lane), t1 = tr_frag_scratch(Sj, 1, lane);
+            q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 0, lane), t0, q0, 0, 0, 0);
+            q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 0, lane), t1, q0, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 1, lane), t0, q1, 0, 0, 0);
+            q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 1, lane), t1, q1, 0, 0, 0);
+        }
+        if (st + 1 < nt) __syncthreads();                      // the scratches are free again
+        if (st == 0) FUSED_STAMP(5);
+    }
+    FUSED_STAMP(6);
+    if (!active) return;
+    if (kvalid) {       // query tile `wave` has the same rows as key tile `wave`
+        bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
+        store_T(drow, q0, q1, scale, hh);
+        store_T(drow + D, dk0, dk1, scale, hh);
+        store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
+    }
+}
+
 // delta[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]: 8 lanes per (token, head), 16-B loads, 3-step shuffle reduce.
 // Its own kernel so that the dQ pass and the dK/dV pass (which both need it) can run concurrently on two streams.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ dout,
@@ -519,7 +717,25 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
 extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo,
                                   const float* lse2, int B, int N, int H, float scale, void* dqkv, int lddqkv,
                                   float* delta, void* stream) {
-    int rc = mofo_attention_delta(out, ldo, dout, lddo, B, N, H, delta, stream);
+    int rc;
+    if (N <= 160 && !getenv("MOFO_ATTN_NO_FUSED_BWD")) {
+        rc = bwd_check("mofo_attention_bwd", qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, dqkv, lddqkv);
+        if (rc) return rc;
+        if (!out || ldo % 8) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_bwd: bad out / ldo");
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void*)attn_bwd_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FUSED_SMEM) != hipSuccess)
+                MOFO_FAIL(MOFO_ERUNTIME, "mofo_attention_bwd: cannot reserve %d bytes of LDS", FUSED_SMEM);
+            attr_set = true;
+        }
+        const float c = scale * 1.4426950408889634f;
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(8 * ceil_div(B * H, 8)), dim3(FUSED_NW * 64), FUSED_SMEM, (hipStream_t)stream,
+                           (const bf16_t*)qkv, ldqkv, B * H, N, H, c, scale, (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse2, delta,
+                           (bf16_t*)dqkv, lddqkv);
+        MOFO_CHECK_LAUNCH("mofo_attention_bwd(fused)");
+        return MOFO_OK;
+    }
+    rc = mofo_attention_delta(out, ldo, dout, lddo, B, N, H, delta, stream);
     if (rc) return rc;
     rc = mofo_attention_bwd_dq(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);
     if (rc) return rc;

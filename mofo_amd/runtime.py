@@ -393,9 +393,13 @@ class PretrainRuntime:
         else:
             # the three passes of mofo_attention_bwd as their own C-ABI calls (same stream, same kernels): each shows up
             # under its own name in the per-class timing
-            ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
-            ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-            ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+            if n <= 160:
+                # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
+                ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
+            else:
+                ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
+                ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+                ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
         ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b, partial_ws=self.ln_ws)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY

@@ -292,6 +292,9 @@ def test_attention_fwd_bwd(dev, B, N, H):
     g = x.grad
     for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         assert _rel(dqkv[:, sl], g[:, sl]) < 2e-2, name
+    # delta = rowsum(dO * O) is an output of the combined entry too (N <= 160: written by the fused kernel)
+    want = (dout.float() * out.float()).view(B, N, H, 64).sum(-1).permute(0, 2, 1).reshape(-1)
+    assert torch.allclose(delta, want, rtol=1e-4, atol=1e-4)
 
 
 def test_attention_bwd_split_entries(dev):

@@ -4,7 +4,7 @@
 Build first, in the container:  python tools/attn_trace.py --build   (attention.hip with -DMOFO_ATTN_TRACE)
 Stamps (wave 0 of every block, key tile 10): 0 tile start | 1 S = K Q^T MFMAs issued | 2 softmax / dS VALU done (operands
 packed) | 3 PV (or dQ) MFMAs issued | 4 next tile written to LDS | 5 barrier passed | 6 next-next tile's global loads issued.
-usage: attn_trace.py <fwd|dq> B N H
+usage: attn_trace.py <fwd|dq|fused> B N H
 """
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -33,7 +33,12 @@ qkv = r(B * N, 3 * H * 64); out = torch.empty(B * N, H * 64, dtype=torch.bfloat1
 dout = r(B * N, H * 64); dqkv = torch.empty_like(qkv); delta = torch.empty_like(lse)
 ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)
 ops.attention_delta(out, dout, B, N, H, delta)
-f = (lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)) if kind == "fwd" else (lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv))
+f = {"fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse),
+     "dq": lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
+     "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta)}[kind]
+names = ["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]
+if kind == "fused":   # N <= 160: the one-kernel backward
+    names = ["issue loads + stage tiles + delta", "barrier", "step 0: pair (S, dP, dS, dV, dK)", "barrier", "step 0: dQ += K^T dS, barrier", "steps 1..T-1"]
 for _ in range(5): f()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -50,6 +55,6 @@ t = buf.reshape(-1, 8)
 t = t[t[:, 0] > 0][:, :7].astype(np.int64)
 d = np.diff(t, axis=1)
 print(f"{len(t)} blocks")
-for i, n in enumerate(["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]):
+for i, n in enumerate(names):
     print(f"  {n:40s} mean {d[:, i].mean():7.0f}  p10 {np.percentile(d[:, i], 10):7.0f}  p50 {np.percentile(d[:, i], 50):7.0f}  p90 {np.percentile(d[:, i], 90):7.0f} clk")
 print(f"  tile total mean {(t[:, 6] - t[:, 0]).mean():.0f} clk")
