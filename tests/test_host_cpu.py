@@ -165,7 +165,8 @@ def test_gradient_segments_tile_the_buffer():
     model = _tiny_model()
     rt, st = _cpu_runtime(model)
     segs = rt.segments
-    assert len(segs) == 3                                             # decoder group + 2 encoder groups (5 blocks -> 3 + 2)
+    assert rt._enc_buckets(12) == [5, 3, 2, 1, 1] and rt._enc_buckets(5) == [2, 2, 1]   # shrinking: the exposed one is the smallest
+    assert len(segs) == 4                                             # decoder group + 3 encoder groups (5 blocks -> 2 + 2 + 1)
     ranges = sorted(segs)
     assert ranges[0][0] == 0 and ranges[-1][1] == st.total
     for (a0, a1), (b0, b1) in zip(ranges, ranges[1:]):
