@@ -218,6 +218,6 @@ def test_data_parallel_gradient_mean_two_ranks(tmp_path):
     for i in range(world):
         assert torch.allclose(r[i]["grads"], mean, rtol=1e-6, atol=1e-7)   # SUM of pre-scaled grads == DDP mean
     assert torch.equal(r[0]["grads"], r[1]["grads"])                   # bit-identical on every rank
-    assert [x[0] for x in r[0]["launched"]] == [0, 1, 2]               # one all-reduce per segment, in completion order
+    assert [x[0] for x in r[0]["launched"]] == [0, 1, 2, 3]            # one all-reduce per segment (decoder + 2, 2, 1 encoder blocks), in completion order
     cover = sorted((lo, hi) for _, lo, hi in r[0]["launched"])
     assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
