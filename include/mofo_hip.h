@@ -148,11 +148,13 @@ int mofo_token_mean_norm(const float* x, int ldx, int B, int N, int D, const flo
  * (utils.py:359), torch.optim.AdamW as configured by optim_factory.py:91-127 (two param groups: decayed / not decayed).
  * n is a multiple of 1024; chunk c covers elements [1024c, 1024c+1024); chunk_group[c] (0/1) selects (lr0,wd0) or
  * (lr1,wd1).  partial f32 [>= 1024] scratch.  If max_norm > 0 the gradient is scaled by min(1, max_norm/(norm+1e-6))
- * with norm read from grad_norm[0] on the device (no host sync). ---- */
+ * with norm read from grad_norm[0] on the device (no host sync).  When no clipping is wanted the norm is not needed
+ * BEFORE the update: pass norm_partial (f32 [>= 2048] scratch) and norm_out and mofo_adamw leaves the global L2 norm of
+ * the gradients it has just read in norm_out[0] (saves mofo_sumsq's extra pass over them); both NULL otherwise. ---- */
 int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, void* stream);
 int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
-               const float* grad_norm, float max_norm, float grad_mult, void* stream);
+               const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream);
 int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 
 #ifdef __cplusplus

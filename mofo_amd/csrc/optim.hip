@@ -41,7 +41,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long long n4,
                                                     const uint8_t* __restrict__ chunk_group, float lr0, float wd0, float lr1,
                                                     float wd1, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
-                                                    const float* __restrict__ grad_norm, float max_norm, float grad_mult) {
+                                                    const float* __restrict__ grad_norm, float max_norm, float grad_mult,
+                                                    float* __restrict__ sumsq_partial) {
+    __shared__ float red[4];
+    float ssq = 0.f;                    // sum of squares of the (unscaled) gradients this thread reads, if asked for
     float gm = grad_mult;
     if (max_norm > 0.f && grad_norm) {
         const float coef = max_norm / (grad_norm[0] * grad_mult + 1e-6f);
@@ -49,7 +52,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 pv = ((f32x4*)p)[i];
-        const f32x4 gv = ((const f32x4*)g)[i] * gm;
+        const f32x4 g0 = ((const f32x4*)g)[i];
+        ssq += g0[0] * g0[0] + g0[1] * g0[1] + g0[2] * g0[2] + g0[3] * g0[3];
+        const f32x4 gv = g0 * gm;
         f32x4 mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
         const bool g1 = chunk_group[i >> 8] != 0;
         const float lr = g1 ? lr1 : lr0;
@@ -69,6 +74,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             ((u32x2*)pb)[i] = pk;
         }
+    }
+    if (sumsq_partial) {                // wave-uniform
+        ssq = wave_sum(ssq);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
+        __syncthreads();
+        if (threadIdx.x == 0) sumsq_partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
     }
 }
 
@@ -100,7 +111,7 @@ extern "C" int mofo_sumsq(const float* g, long long n, float* partial, float* ou
 
 extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
                           float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
-                          const float* grad_norm, float max_norm, float grad_mult, void* stream) {
+                          const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream) {
     if (!p || !g || !m || !v || !chunk_group) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: null pointer");
     if (n <= 0 || n % 1024) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_adamw: n must be a positive multiple of 1024");
     if (step < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: step starts at 1");
@@ -109,8 +120,13 @@ extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_
     const float inv_bc1 = (float)(1.0 / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
-                       chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult);
+                       chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
+                       (norm_partial && norm_out) ? norm_partial : nullptr);
     MOFO_CHECK_LAUNCH("mofo_adamw");
+    if (norm_partial && norm_out) {     // global gradient L2 norm as a by-product of the pass that reads the gradients anyway
+        hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)norm_partial, stream_blocks(n / 4), norm_out);
+        MOFO_CHECK_LAUNCH("mofo_adamw(norm)");
+    }
     return MOFO_OK;
 }
 

@@ -404,7 +404,9 @@ def sumsq_norm(g, partial, out_norm):
     return out_norm
 
 
-def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0):
+def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0,
+          norm_partial=None, norm_out=None):
+    """``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out"""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, n, 1)
     _chk(chunk_group, U8, "chunk_group", 1)
@@ -415,8 +417,14 @@ def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps
         _chk(p_bf16, BF16, "p_bf16", 1)
         if p_bf16.numel() != n:
             raise ValueError("p_bf16 length")
+    if (norm_partial is None) != (norm_out is None):
+        raise ValueError("adamw: norm_partial and norm_out go together")
+    if norm_out is not None:
+        _chk(norm_partial, F32, "norm_partial", 1), _chk(norm_out, F32, "norm_out")
+        if norm_partial.numel() < 2048:
+            raise ValueError("norm_partial must hold 2048 floats")
     _run("mofo_adamw", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
-         lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult)
+         lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out))
 
 
 def cast_bf16(src, dst):

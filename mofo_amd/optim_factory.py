@@ -72,18 +72,27 @@ class FusedAdamW(torch.optim.Optimizer):
         return self.param_groups[0]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_norm=None, max_norm=0.0):
+    def step(self, closure=None, grad_norm=None, max_norm=0.0, norm_out=None):
+        """``norm_out`` (device f32 [1], only without clipping): the update pass also leaves the global gradient L2 norm
+        there -- the norm is reported, not needed before the update, so the gradients are read once instead of twice"""
         if closure is not None:
             raise NotImplementedError("closure")
-        _, st = self._bind()
+        rt, st = self._bind()
         g0 = next(g for g in self.param_groups if g["_decayed"]) if any(g.get("_decayed") for g in self.param_groups) else self.param_groups[0]
         g1 = next((g for g in self.param_groups if not g["_decayed"]), g0)
         self._step += 1
         b1, b2 = g0["betas"]
+        partial = None
+        if norm_out is not None:
+            if max_norm:
+                raise ValueError("norm_out is for the un-clipped step (clipping needs the norm before the update)")
+            if getattr(self, "_norm_partial", None) is None or self._norm_partial.device != st.params.device:
+                self._norm_partial = torch.empty(2048, dtype=torch.float32, device=st.params.device)
+            partial = self._norm_partial
         ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group,
                   float(g0["lr"]), float(g0["weight_decay"]), float(g1["lr"]), float(g1["weight_decay"]),
                   float(b1), float(b2), float(g0["eps"]), self._step, grad_norm=grad_norm,
-                  max_norm=float(max_norm) if max_norm else 0.0)
+                  max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out)
         st.mark_shadow_fresh()
 
     # checkpoint.  Written in torch.optim.AdamW's own state_dict layout -- state[i] = {'step','exp_avg','exp_avg_sq'} with i

@@ -180,8 +180,13 @@ class NativeScalerWithGradNormCount:
         sync = getattr(model, "_grad_sync", None)
         if sync is not None:
             sync.finish()              # data-parallel all-reduces launched during backward
-        norm = model.runtime().grad_norm()     # utils.py:376-388, device scalar
-        optimizer.step(grad_norm=norm, max_norm=clip_grad if clip_grad else 0.0)
+        rt = model.runtime()
+        if not clip_grad:
+            # utils.py:376-388: the norm is only REPORTED here, so the AdamW pass computes it from the gradients it reads anyway
+            optimizer.step(norm_out=rt.norm_out)
+            return rt.norm_out
+        norm = rt.grad_norm()                  # utils.py:376-388, device scalar; needed before the update for clip_grad_norm_
+        optimizer.step(grad_norm=norm, max_norm=clip_grad)
         return norm
 
     def state_dict(self):

@@ -492,6 +492,12 @@ def test_sumsq_adamw_cast(dev):
     ops.adamw(p2, g, m2, v2, None, grp, lr0, 0.0, lr0, 0.0, 0.9, 0.95, 1e-8, 1, grad_norm=norm, max_norm=0.5)
     coef = 0.5 / (float(norm.item()) + 1e-6)
     assert _rel(m2, 0.1 * g * coef) < 1e-5
+    # the un-clipped step can leave the gradient norm as a by-product (no separate pass over g)
+    p3, m3, v3 = p.clone(), torch.zeros_like(p), torch.zeros_like(p)
+    np_, no_ = torch.empty(2048, dtype=F32, device=dev), torch.zeros(1, dtype=F32, device=dev)
+    ops.adamw(p3, g, m3, v3, None, grp, lr0, 0.0, lr0, 0.0, 0.9, 0.95, 1e-8, 1, norm_partial=np_, norm_out=no_)
+    assert float(no_.item()) == pytest.approx(float(g.double().norm()), rel=1e-6)
+    assert _rel(m3, 0.1 * g) < 1e-6
     dst = torch.empty(n, dtype=BF16, device=dev)
     ops.cast_bf16(p, dst)
     assert torch.equal(dst, p.to(BF16))
