@@ -77,6 +77,12 @@ int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const float* x, int ldx, c
                        const void* dres_bf16, int lddres_bf16,
                        float* partial_ws /* >= 2*1024*D floats of scratch, or NULL: NULL falls back to contended atomics */,
                        void* stream);
+/* Deferred reduction: called with dw = db = NULL (and a partial_ws of its own) mofo_layernorm_bwd leaves only the
+ * mofo_layernorm_bwd_blocks(M) block partials in partial_ws; mofo_layernorm_bwd_finalize adds the partials of up to 8
+ * LayerNorms to their dw / db in one launch (34 per-LayerNorm reduction launches per ViT-B step become 6). */
+int mofo_layernorm_bwd_blocks(int M);
+int mofo_layernorm_bwd_finalize(const float* const* partials, const int* nblocks, const int* Ds, float* const* dws,
+                                float* const* dbs, int count, void* stream);
 
 /* ---- multi-head self-attention core: modeling_finetune.py:85-95 (q*scale, q@k^T, softmax, @v).
  * qkv is the fused projection output, bf16 [B*N, 3*H*64] (q | k | v, each head-major x 64); head_dim is 64 in every

@@ -34,6 +34,8 @@ _SIGS = {
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mofo_layernorm_bwd_blocks": (_i, [_i]),
+    "mofo_layernorm_bwd_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_attention_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
     "mofo_ingest_u8": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -208,6 +208,35 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
     if (part == 0 && c < D && b0 < b1) atomicAdd((which ? db : dw) + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
 }
 
+// The same for up to FIN_MAX LayerNorms in ONE launch: the per-LayerNorm launch cost 6 us x 34 per step for 0.1 us of work;
+// the runtime now lets a gradient bucket's LayerNorms leave their block partials in separate workspaces and reduces them
+// together before the bucket's all-reduce / the optimizer needs them.
+constexpr int FIN_MAX = 8;
+struct FinItems {
+    const float* partial[FIN_MAX];
+    float* dw[FIN_MAX];
+    float* db[FIN_MAX];
+    int nblocks[FIN_MAX];
+    int D[FIN_MAX];
+};
+__global__ __launch_bounds__(256) void ln_bwd_finalize_grouped_kernel(FinItems it) {
+    __shared__ float red[4][64];
+    const int item = blockIdx.z / FIN_SLICES, slice = blockIdx.z % FIN_SLICES;
+    const float* partial = it.partial[item];
+    const int nblocks = it.nblocks[item], D = it.D[item];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int which = blockIdx.y;
+    const int c = blockIdx.x * 64 + cl;
+    const int per = (nblocks + FIN_SLICES - 1) / FIN_SLICES;
+    const int b0 = slice * per, b1 = min(nblocks, b0 + per);
+    float s = 0.f;
+    if (c < D)
+        for (int b = b0 + part; b < b1; b += 4) s += partial[((size_t)b * 2 + which) * D + c];
+    red[part][cl] = s;
+    __syncthreads();
+    if (part == 0 && c < D && b0 < b1) atomicAdd((which ? it.db[item] : it.dw[item]) + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
+}
+
 // Mean pooling over a clip's tokens + fc_norm of the fine-tune / feature-extraction model (modeling_finetune.py:403-405:
 // `self.fc_norm(x.mean(1))`).  Stage 1: every block adds 32 token rows of one clip into pooled[b, :] (f32 atomics: B*D
 // addresses, N/32 adds each).  Stage 2: one block per clip scales by 1/N and applies LayerNorm; writes f32 and bf16.
@@ -277,11 +306,17 @@ extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const
     return MOFO_OK;
 }
 
+extern "C" int mofo_layernorm_bwd_blocks(int M) {
+    int blocks = ceil_div(M, 8);
+    return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
+}
+
 extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
                                   int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
                                   const void* dresb, int lddresb, float* partial_ws, void* stream) {
-    if (!dy || !x || !w || !mean || !rstd || !dw || !db) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
+    const bool defer = partial_ws && !dw && !db;      // block partials only; mofo_layernorm_bwd_finalize reduces them later
+    if (!dy || !x || !w || !mean || !rstd || (!defer && (!dw || !db))) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
     if (!dx && !dxb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: need dx (f32) and/or dx_bf16");
     if (dres && dresb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: pass the residual gradient as f32 OR bf16, not both");
     int rc = ln_check("mofo_layernorm_bwd", M, D, rows_in, rows_out);
@@ -292,18 +327,34 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
     const int nit = ceil_div(D, 256);
     // every block pays a fixed cost (weight load, LDS reduce, 2 D atomics); 2 rows per wave keeps >= 2 blocks per CU busy
     // at the encoder's M = 5120 while bounding the atomic traffic (1024 blocks x 2 D floats)
-    int blocks = ceil_div(M, 8);
-    if (blocks > 1024) blocks = 1024;
-    if (blocks < 1) blocks = 1;
+    const int blocks = mofo_layernorm_bwd_blocks(M);
     dim3 grid(blocks), block(256);
 #define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_bwd");
-    if (partial_ws) {
+    if (partial_ws && !defer) {
         hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3(ceil_div(D, 64), 2, FIN_SLICES), dim3(256), 0, s, (const float*)partial_ws, blocks, D, dw, db);
         MOFO_CHECK_LAUNCH("mofo_layernorm_bwd(finalize)");
     }
+    return MOFO_OK;
+}
+
+extern "C" int mofo_layernorm_bwd_finalize(const float* const* partials, const int* nblocks, const int* Ds, float* const* dws,
+                                           float* const* dbs, int count, void* stream) {
+    if (!partials || !nblocks || !Ds || !dws || !dbs) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd_finalize: null pointer");
+    if (count < 1 || count > FIN_MAX) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd_finalize: count must be 1..%d", FIN_MAX);
+    FinItems it;
+    int dmax = 0;
+    for (int i = 0; i < FIN_MAX; ++i) {
+        const int k = i < count ? i : 0;
+        if (!partials[k] || !dws[k] || !dbs[k] || nblocks[k] < 1 || nblocks[k] > 1024 || Ds[k] < 1)
+            MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd_finalize: bad item %d", k);
+        it.partial[i] = partials[k]; it.dw[i] = dws[k]; it.db[i] = dbs[k]; it.nblocks[i] = nblocks[k]; it.D[i] = Ds[k];
+        if (Ds[k] > dmax) dmax = Ds[k];
+    }
+    hipLaunchKernelGGL(ln_bwd_finalize_grouped_kernel, dim3(ceil_div(dmax, 64), 2, FIN_SLICES * count), dim3(256), 0, (hipStream_t)stream, it);
+    MOFO_CHECK_LAUNCH("mofo_layernorm_bwd_finalize");
     return MOFO_OK;
 }
 

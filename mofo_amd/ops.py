@@ -204,7 +204,13 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
 def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):
     """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
     (bf16) are the outputs, either may be None but not both."""
-    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
+    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1)
+    defer = dw is None and db is None
+    if defer:
+        if partial_ws is None:
+            raise ValueError("layernorm_bwd: deferred reduction (dw = db = None) needs its own partial_ws")
+    else:
+        _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
     D = x.shape[1]
     M = dy.shape[0] if M is None else M
     rows_in = M if rows_in is None else rows_in
@@ -227,7 +233,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         _chk(dxb, BF16, "dxb", 2)
         if dxb.shape != x.shape:
             raise ValueError("dxb shape")
-    if dy.shape[1] != D or dw.numel() != D or db.numel() != D or dy.shape[0] < M:
+    if dy.shape[1] != D or (not defer and (dw.numel() != D or db.numel() != D)) or dy.shape[0] < M:
         raise ValueError("layernorm_bwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_bwd: row map exceeds x")
@@ -241,6 +247,23 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
          _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
          rows_in, rows_out, row_off, _p(dx), _ld(dx) if dx is not None else 0, _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
          _p(dres_b), _ld(dres_b) if dres_b is not None else 0, _p(partial_ws))
+    return _lib.load().mofo_layernorm_bwd_blocks(M) if defer else None
+
+
+def layernorm_bwd_finalize(items):
+    """items = [(partial_ws, nblocks, D, dw, db), ...] (at most 8) left behind by deferred layernorm_bwd calls: one launch
+    adds every LayerNorm's block partials to its dw / db"""
+    n = len(items)
+    if not 1 <= n <= 8:
+        raise ValueError("layernorm_bwd_finalize: 1..8 items")
+    for ws, nb, D, dw, db in items:
+        _chk(ws, F32, "partial_ws", 1), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
+        if dw.numel() != D or db.numel() != D or ws.numel() < 2 * nb * D or not 1 <= nb <= 1024:
+            raise ValueError("layernorm_bwd_finalize: item shape mismatch")
+    vp, ci = C.c_void_p * n, C.c_int * n
+    args = (vp(*[t[0].data_ptr() for t in items]), ci(*[t[1] for t in items]), ci(*[t[2] for t in items]),
+            vp(*[t[3].data_ptr() for t in items]), vp(*[t[4].data_ptr() for t in items]))
+    _run("mofo_layernorm_bwd_finalize", ("ln_bwd_fin",), sum(8.0 * t[1] * t[2] for t in items), *args, n)
 
 
 def attention_fwd(qkv, B, N, H, scale, out, lse2):

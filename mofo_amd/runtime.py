@@ -233,7 +233,27 @@ class PretrainRuntime:
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)
         self.ln_ws = torch.empty(2 * 1024 * dmax, dtype=F32, device=self.dev)   # LN-backward dgamma/dbeta block partials
+        self._ln_dmax, self._ln_pool, self._ln_pending = dmax, [], []
         self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
+
+    # ------------------------------------------------------------------ LayerNorm backward with grouped dgamma / dbeta reduction
+    def _ln_bwd(self, dy, x, w, mean, rstd, dres, dx, dxb, gw, gb, **kw):
+        """ops.layernorm_bwd whose dgamma / dbeta block partials stay in a workspace of their own; ``_ln_flush`` reduces up
+        to eight LayerNorms' partials in one launch (before a gradient bucket is handed to the all-reduce / optimizer)"""
+        if len(self._ln_pending) == 8:
+            self._ln_flush()
+        D = x.shape[1]
+        k = len(self._ln_pending)
+        if k >= len(self._ln_pool):
+            self._ln_pool.append(torch.empty(2 * 1024 * self._ln_dmax, dtype=F32, device=self.dev))
+        ws = self._ln_pool[k]
+        nb = ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, None, None, partial_ws=ws, **kw)
+        self._ln_pending.append((ws, nb, D, gw, gb))
+
+    def _ln_flush(self):
+        if self._ln_pending:
+            ops.layernorm_bwd_finalize(self._ln_pending)
+            self._ln_pending = []
 
     # ------------------------------------------------------------------ weights
     def _block_weights(self, p):
@@ -374,7 +394,7 @@ class PretrainRuntime:
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, T.dh1, aux=L.h1)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dh1, W.fc1, S.dxln)
-        ops.layernorm_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b, partial_ws=self.ln_ws)
+        self._ln_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
         if n > 512 and self.side2 is not None and os.environ.get("MOFO_ATTN_CONCURRENT", "0") == "1":
@@ -401,7 +421,7 @@ class PretrainRuntime:
                 ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
                 ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
-        ops.layernorm_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b, partial_ws=self.ln_ws)
+        self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
         ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
@@ -505,8 +525,8 @@ class PretrainRuntime:
         d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
         S.used = [False, False]
-        ops.layernorm_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
-                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), partial_ws=self.ln_ws)
+        self._ln_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
+                     s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
         j = 0
         # bucket boundaries (block index after which a gradient range is complete), as plan_segments laid them out
@@ -519,10 +539,12 @@ class PretrainRuntime:
             self._block_bwd(self.encW[i], w.enc[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.n_vis, d.enc_heads)
             j += 1
             if i in ends:
+                self._ln_flush()
                 self._join_side(S)
                 self._seg(seg)
                 seg += 1
         self._wgrad(S.ring[j % 3], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
+        self._ln_flush()
         self._join_side(S)
         self._seg(seg)
 
@@ -562,14 +584,14 @@ class PretrainRuntime:
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
         S.used = [False, False]
         ops.host_op(lambda: S.ring[0].zero_())
-        ops.layernorm_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
-                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret,
-                          partial_ws=self.ln_ws)
+        self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
+                     s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         j = 0
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
             self._block_bwd(self.decW[i], w.dec[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.N, d.dec_heads)
             j += 1
+        self._ln_flush()
         self._join_side(S)
         return S.ring[j % 3]       # gradient wrt the decoder input, bf16 [B*N, D]
 

@@ -235,6 +235,36 @@ def test_layernorm_fwd_bwd(dev, M, D):
     assert _rel(dw - 0.25, wr.grad) < 1e-4 and _rel(db + 0.5, br.grad) < 1e-4
 
 
+def test_layernorm_bwd_deferred_grouped_finalize(dev):
+    """dw = db = None: only block partials are written; ONE grouped launch reduces several LayerNorms (what the step does)"""
+    from mofo_amd import ops
+    items, want = [], []
+    for k, (M, D) in enumerate([(320, 768), (3136, 384), (33, 512)]):
+        x = _rand((M, D), dev, 10 + k, 2.0, F32)
+        w = _rand((D,), dev, 20 + k, 0.3, F32) + 1.0
+        y = torch.empty(M, D, dtype=BF16, device=dev)
+        mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+        ops.layernorm_fwd(x, w, torch.zeros_like(w), 1e-6, y, mean, rstd)
+        dy = _rand((M, D), dev, 30 + k)
+        dxb = torch.empty(M, D, dtype=BF16, device=dev)
+        ref_dw, ref_db = torch.full((D,), 0.5, dtype=F32, device=dev), torch.full((D,), -1.0, dtype=F32, device=dev)
+        ws0 = torch.empty(2 * 1024 * D, dtype=F32, device=dev)
+        ops.layernorm_bwd(dy, x, w, mean, rstd, None, None, dxb, ref_dw, ref_db, partial_ws=ws0)        # immediate form
+        dw, db = torch.full((D,), 0.5, dtype=F32, device=dev), torch.full((D,), -1.0, dtype=F32, device=dev)
+        ws = torch.empty(2 * 1024 * D, dtype=F32, device=dev)
+        dxb2 = torch.empty_like(dxb)
+        nb = ops.layernorm_bwd(dy, x, w, mean, rstd, None, None, dxb2, None, None, partial_ws=ws)      # deferred
+        assert nb == min(1024, -(-M // 8)) and torch.equal(dxb2, dxb)
+        assert torch.all(dw == 0.5) and torch.all(db == -1.0)                                             # nothing added yet
+        items.append((ws, nb, D, dw, db))
+        want.append((ref_dw, ref_db))
+    ops.layernorm_bwd_finalize(items)
+    for (_, _, _, dw, db), (rw, rb) in zip(items, want):
+        assert torch.allclose(dw, rw, rtol=1e-5, atol=1e-5) and torch.allclose(db, rb, rtol=1e-5, atol=1e-5)
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd_finalize(items * 3)
+
+
 def test_layernorm_rowmap(dev):
     """decoder final norm: only the last n_msk rows of every clip (modeling_pretrain.py:157)."""
     from mofo_amd import ops
