@@ -15,110 +15,91 @@ import torch.distributed as dist
 
 
 # ----------------------------------------------------------------------------------------------- meters
-class SmoothedValue(object):
-    """utils.py:27-86"""
+class SmoothedValue:
+    """Windowed + global statistics of one scalar series; public surface of the reference's meter (utils.py:27-86):
+    ``update``, ``median`` / ``avg`` (window), ``global_avg``, ``max``, ``value``, ``count`` / ``total``, ``fmt``, str()."""
 
     def __init__(self, window_size=20, fmt=None):
-        self.deque = deque(maxlen=window_size)
-        self.total = 0.0
-        self.count = 0
-        self.fmt = fmt or "{median:.4f} ({global_avg:.4f})"
+        self._win = deque(maxlen=window_size)
+        self.count, self.total = 0, 0.0
+        self.fmt = "{median:.4f} ({global_avg:.4f})" if fmt is None else fmt
 
     def update(self, value, n=1):
-        self.deque.append(value)
+        self._win.append(value)
         self.count += n
         self.total += value * n
 
     def synchronize_between_processes(self):
-        """utils.py:45-56: all-reduce (count, total); the window is left local"""
+        """sum (count, total) over the ranks; the window stays local (utils.py:45-56)"""
         if not is_dist_avail_and_initialized():
             return
-        dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
-        t = torch.tensor([self.count, self.total], dtype=torch.float64, device=dev)
+        where = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+        pair = torch.tensor([float(self.count), self.total], dtype=torch.float64, device=where)
         dist.barrier()
-        dist.all_reduce(t)
-        t = t.tolist()
-        self.count = int(t[0])
-        self.total = t[1]
+        dist.all_reduce(pair)
+        self.count, self.total = int(pair[0].item()), float(pair[1].item())
 
-    @property
-    def median(self):
-        return torch.tensor(list(self.deque)).median().item()
-
-    @property
-    def avg(self):
-        return torch.tensor(list(self.deque), dtype=torch.float32).mean().item()
-
-    @property
-    def global_avg(self):
-        return self.total / self.count
-
-    @property
-    def max(self):
-        return max(self.deque)
-
-    @property
-    def value(self):
-        return self.deque[-1]
+    # window statistics; torch.median semantics (lower of the two middle values) as the reference prints them
+    median = property(lambda self: float(np.sort(np.asarray(self._win, dtype=np.float64))[(len(self._win) - 1) // 2]))
+    avg = property(lambda self: float(np.mean(np.asarray(self._win, dtype=np.float32))))
+    global_avg = property(lambda self: self.total / self.count)
+    max = property(lambda self: max(self._win))
+    value = property(lambda self: self._win[-1])
 
     def __str__(self):
         return self.fmt.format(median=self.median, avg=self.avg, global_avg=self.global_avg, max=self.max, value=self.value)
 
 
-class MetricLogger(object):
-    """utils.py:89-170"""
+class MetricLogger:
+    """Named meters + the progress printer of the epoch loop (utils.py:89-170): ``update(**scalars)``, attribute access to
+    meters, ``add_meter``, ``synchronize_between_processes``, ``log_every(iterable, print_freq, header)``."""
 
     def __init__(self, delimiter="\t"):
         self.meters = defaultdict(SmoothedValue)
         self.delimiter = delimiter
 
-    def update(self, **kwargs):
-        for k, v in kwargs.items():
-            if v is None:
+    def update(self, **scalars):
+        for name, val in scalars.items():
+            if val is None:
                 continue
-            if isinstance(v, torch.Tensor):
-                v = v.item()
-            assert isinstance(v, (float, int))
-            self.meters[k].update(v)
+            val = val.item() if isinstance(val, torch.Tensor) else val
+            if not isinstance(val, (float, int)):
+                raise TypeError(f"meter {name}: {type(val).__name__} is not a scalar")
+            self.meters[name].update(val)
 
-    def __getattr__(self, attr):
-        if attr in self.meters:
-            return self.meters[attr]
-        if attr in self.__dict__:
-            return self.__dict__[attr]
-        raise AttributeError("'{}' object has no attribute '{}'".format(type(self).__name__, attr))
+    def __getattr__(self, name):
+        meters = self.__dict__.get("meters", {})
+        if name in meters:
+            return meters[name]
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
 
     def __str__(self):
-        return self.delimiter.join("{}: {}".format(name, str(meter)) for name, meter in self.meters.items())
-
-    def synchronize_between_processes(self):
-        for meter in self.meters.values():
-            meter.synchronize_between_processes()
+        return self.delimiter.join(f"{k}: {m}" for k, m in self.meters.items())
 
     def add_meter(self, name, meter):
         self.meters[name] = meter
 
+    def synchronize_between_processes(self):
+        for m in self.meters.values():
+            m.synchronize_between_processes()
+
     def log_every(self, iterable, print_freq, header=None):
-        i = 0
         header = header or ''
-        start_time = time.time()
-        end = time.time()
-        iter_time = SmoothedValue(fmt='{avg:.4f}')
-        data_time = SmoothedValue(fmt='{avg:.4f}')
-        n = len(iterable)
-        space_fmt = ':' + str(len(str(n))) + 'd'
-        log_msg = self.delimiter.join([header, '[{0' + space_fmt + '}/{1}]', 'eta: {eta}', '{meters}', 'time: {time}', 'data: {data}'])
-        for obj in iterable:
-            data_time.update(time.time() - end)
-            yield obj
-            iter_time.update(time.time() - end)
-            if i % print_freq == 0 or i == n - 1:
-                eta = str(datetime.timedelta(seconds=int(iter_time.global_avg * (n - i))))
-                print(log_msg.format(i, n, eta=eta, meters=str(self), time=str(iter_time), data=str(data_time)))
-            i += 1
-            end = time.time()
-        total = time.time() - start_time
-        print('{} Total time: {} ({:.4f} s / it)'.format(header, str(datetime.timedelta(seconds=int(total))), total / max(n, 1)))
+        total = len(iterable)
+        width = len(str(total))
+        step_time, wait_time = SmoothedValue(fmt='{avg:.4f}'), SmoothedValue(fmt='{avg:.4f}')
+        t_start = t_mark = time.time()
+        for i, item in enumerate(iterable):
+            wait_time.update(time.time() - t_mark)
+            yield item
+            step_time.update(time.time() - t_mark)
+            if i % print_freq == 0 or i == total - 1:
+                eta = datetime.timedelta(seconds=int(step_time.global_avg * (total - i)))
+                fields = [header, f"[{i:{width}d}/{total}]", f"eta: {eta}", str(self), f"time: {step_time}", f"data: {wait_time}"]
+                print(self.delimiter.join(fields))
+            t_mark = time.time()
+        spent = time.time() - t_start
+        print(f"{header} Total time: {datetime.timedelta(seconds=int(spent))} ({spent / max(total, 1):.4f} s / it)")
 
 
 # ----------------------------------------------------------------------------------------------- distributed
