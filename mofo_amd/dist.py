@@ -54,7 +54,9 @@ class DataParallel(torch.nn.Module):
         self.module = module
         self.sync = GradSync(module, process_group).install()
         if self.sync.enabled:
-            dist.broadcast(module.runtime().store.params, src=0, group=process_group)
+            store = module.runtime().store
+            dist.broadcast(store.params, src=0, group=process_group)
+            store._shadow_version = -1          # the bf16 shadow is rebuilt from the received masters at the next forward
         self.world_size = dist.get_world_size(process_group) if self.sync.enabled else 1
 
     def forward(self, *a, **k):
