@@ -221,3 +221,28 @@ def test_data_parallel_gradient_mean_two_ranks(tmp_path):
     assert [x[0] for x in r[0]["launched"]] == [0, 1, 2, 3]            # one all-reduce per segment (decoder + 2, 2, 1 encoder blocks), in completion order
     cover = sorted((lo, hi) for _, lo, hi in r[0]["launched"])
     assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+
+
+# ------------------------------------------------------------------------------------------------ "next" rows
+def test_finetune_model_schema_and_checkpoint_mapping():
+    """state_dict schema of the fine-tune model = the reference's (oracle.finetune_param_shapes, pinned by finetune_*.npz), a
+    pretraining checkpoint maps onto it the way run_class_finetuning.py:362-411 does, and the forward refuses the CPU"""
+    from mofo_amd import modeling_finetune as ft
+    from mofo_amd import modeling_pretrain as mp
+    from oracle import pretrain_oracle as O
+    m = ft.vit_base_patch16_224(num_classes=400, all_frames=16, tubelet_size=2)
+    shapes = O.finetune_param_shapes(O.VIT_B, 400)
+    sd = m.state_dict()
+    assert list(sd) == list(shapes) and all(tuple(sd[k].shape) == shapes[k] for k in sd)
+    assert isinstance(m.norm, torch.nn.Identity) and m.get_num_layers() == 12 and m.patch_embed.num_patches == 1568
+    pre = mp.pretrain_videomae_base_patch16_224(decoder_depth=1)
+    r = m.load_pretrained_encoder(pre.state_dict())
+    assert sorted(r.missing_keys) == ["fc_norm.bias", "fc_norm.weight", "head.bias", "head.weight"] and not r.unexpected_keys
+    assert torch.equal(m.state_dict()["blocks.3.attn.qkv.weight"], pre.state_dict()["encoder.blocks.3.attn.qkv.weight"])
+    with pytest.raises(RuntimeError, match="GPU only"):
+        m(torch.zeros(1, 3, 16, 224, 224))
+    for kw in (dict(use_mean_pooling=False), dict(init_values=0.1), dict(use_learnable_pos_emb=True)):
+        with pytest.raises(NotImplementedError):
+            ft.vit_base_patch16_224(num_classes=400, **kw)
+    feat = ft.vit_base_patch16_224_feature_ext(num_classes=400)
+    assert type(feat).__name__ == "VisionTransformer_feat_ext"
