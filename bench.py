@@ -203,6 +203,22 @@ def main():
                            "unit": "TFLOP/s" if is_mfma else "GB/s", "frac": round(ach / (PEAK_BF16 if is_mfma else PEAK_HBM), 4),
                            "traffic": None, "launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
                            "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
+        # HBM-side traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
+        # (tools/pmc_step.sh; FETCH_SIZE doubled as the guide prescribes for gfx950), committed under profiles/ -- counters
+        # cannot be read from inside the process, so this is the recorded figure, null if the file is absent
+        kern = {"gemm_tn_wgrad_f32": "gemm_kernel<1, 1, 5, 1, 4>"}.get(out["roofline"]["kernel"])
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
+        if kern and os.path.exists(tpath):
+            try:
+                rec = json.load(open(tpath)).get(kern)
+                if rec:
+                    out["roofline"]["traffic"] = round((rec["fetch_MB_per_launch"] + rec["write_MB_per_launch"]) * 1e6)
+                    out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 PMC passes of this command, profiles/r01_pmc_step_traffic.json)"
+                    if kern.startswith("gemm_kernel<1, 1, 5"):
+                        # operands read once + f32 weight gradients written once, averaged over the step's 19 launches
+                        out["roofline"]["algorithmic_bytes"] = round((4186.0e6 + 377.0e6) / 19)
+            except Exception:
+                pass
         gem = [warm[k] for k in warm if k[0] == "gemm"]
         if gem:
             out["roofline"]["all_gemm_tflops"] = round(sum(g["work"] for g in gem) / sum(g["ms"] for g in gem) / 1e9, 2)

@@ -318,25 +318,29 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
     const int wm = wave >> 1, wn = wave & 1;
     MOFO_TRACE(0);
     MOFO_TRACE_ID();
+    // XCD-aware order (8 XCDs with private L2s; blocks b and b+8 share an XCD): every XCD takes ONE contiguous run of the
+    // whole launch's (problem, split, tile) list, and inside a problem the tiles run along the SHORTER side of the tile grid
+    // first, so an XCD's run is a few full short-side stripes: it fetches each operand panel once.  (Spreading every problem
+    // of a grouped weight-gradient launch over all 8 XCDs made each XCD fetch most panels of every problem: PMC on the step
+    // showed 502 MB fetched per wgrad launch for 220 MB of operands.)
+    int w = blockIdx.x;
+    {
+        const int total = G.start[G.count];
+        const int q = total >> 3, r = total & 7, xcd = w & 7;
+        w = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+    }
     int gi = 0;
 #pragma unroll
     for (int k = 1; k < MAXG; ++k)
-        if (k < G.count && (int)blockIdx.x >= G.start[k]) gi = k;
+        if (k < G.count && w >= G.start[k]) gi = k;
     const GemmP p = G.p[gi];
-
-    // XCD-aware remap (8 XCDs, private L2s): blocks b and b+8 share an XCD, so give each XCD a contiguous
-    // run of tiles with n fastest; the B panel (weights) and one A row-panel then stay L2-resident per XCD.
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int tiles = tiles_n * ((p.M + BMT - 1) / BMT);
-    const int nwg = G.start[gi + 1] - G.start[gi];
-    int wg = blockIdx.x - G.start[gi];
-    {
-        const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (wg >> 3);
-    }
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BMT - 1) / BMT;
+    const int tiles = tiles_n * tiles_m;
+    int wg = w - G.start[gi];
     const int split = wg / tiles;
     wg -= split * tiles;
-    const int m0 = (wg / tiles_n) * BMT, n0 = (wg % tiles_n) * BN;
+    const int m0 = (tiles_n <= tiles_m ? wg / tiles_n : wg % tiles_m) * BMT;
+    const int n0 = (tiles_n <= tiles_m ? wg % tiles_n : wg / tiles_m) * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nk = (kend - kbeg + BK - 1) / BK;
