@@ -45,6 +45,7 @@ struct GemmP {
     int atomic;
     float* colsum;            // TN only: colsum[m] += sum_k A[k,m]  (bias gradient riding on the wgrad GEMM), or null
     int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
+    int rotate;               // persistent form: rotated reduction order per tile (see gemm_persistent_kernel)
 };
 
 constexpr int MAXG = 4;
@@ -510,9 +511,16 @@ __global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int to
     int va0, va1, vb0, vb1;
     srd_lane_offsets<LA>(p.lda, lane, va0, va1);
     srd_lane_offsets<LB>(p.ldb, lane, vb0, vb1);
+    // k-stage t of tile (m0, n0) is reduction chunk (t + m-tile index + n-tile index) mod nk: the co-resident blocks that share
+    // an operand panel (same m-tile: the A rows; same n-tile: the weights) walk the reduction in ROTATED order.  In step they
+    // all ask for the same lines at the same moment (PMC on the step: the decoder's fc1 GEMM fetches ~4x its operand bytes
+    // either way -- the L2 does not merge the concurrent misses -- but rotated the requests spread over the memory channels).
+    // Used where it measured faster (p.rotate, set in fill_problem).
     auto stage = [&](int m0, int n0, int t) {
-        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, t * BK, smem, wave_u);
-        stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, t * BK, smem + A_BYTES, wave_u);
+        int kc = t + m0 / BMT + n0 / BN;
+        kc = p.rotate ? kc % nk : t;
+        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
+        stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, kc * BK, smem + A_BYTES, wave_u);
     };
     const unsigned char* ta = smem;
     const unsigned char* tb = smem + A_BYTES;
@@ -765,6 +773,18 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
     p.colsum = a->colsum;
     p.colsum_skip_lo = a->colsum_skip_lo;
     p.colsum_skip_hi = a->colsum_skip_hi;
+    {
+        // rotated reduction order (gemm_persistent_kernel): measured per class on one box -- fc1 + GELU forward (12 / 24 n-tiles
+        // share an A panel, long epilogue) 126 -> 106 us (decoder), 38.0 -> 37.2 (encoder); neutral for the other wide-N
+        // GEMMs; 5-10 % SLOWER for the N = 384 ones (3 n-tiles: little to de-duplicate, and the block's own row panel is no
+        // longer streamed in order).  MOFO_GEMM_ROTATE=0|1 forces it off / on for every persistent GEMM.
+        static int rot = -2;
+        if (rot == -2) {
+            const char* e = getenv("MOFO_GEMM_ROTATE");
+            rot = e ? atoi(e) : -1;
+        }
+        p.rotate = rot >= 0 ? rot : (op == MOFO_GEMM_NT && epi == MOFO_EPI_BIAS_GELU);
+    }
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
     blocks = ceil_div(a->M, bm) * ceil_div(a->N, BN) * splits;
     return MOFO_OK;
