@@ -625,8 +625,14 @@ __global__ __launch_bounds__(512, 2) void gemm_ksplit_kernel(GemmP p, int total)
     unsigned char* gs = smem + grp_u * STG;
     // NT: both operands are k-contiguous rows -- a k offset past K inside the LAST row would be in range, so an empty
     // trailing k-stage is skipped explicitly (nk odd); NN's B rows past K are out of range by themselves.
+    const int krot = p.rotate_tile ? (m0 / BMT + n0 / BN) % nkh : 0;     // rotated reduction order, see gemm_persistent_kernel
+    auto kof = [&](int t) {
+        int kc = t + krot;
+        kc = kc >= nkh ? kc - nkh : kc;
+        return kb + kc * BK;
+    };
     auto stage = [&](int t) {
-        const int k0 = kb + t * BK;
+        const int k0 = kof(t);
         if (k0 < p.K) {
             stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, k0, gs, w4_u);
             stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, k0, gs + A_BYTES, w4_u);
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(512, 2) void gemm_ksplit_kernel(GemmP p, int total)
     const unsigned char* ta = gs;
     const unsigned char* tb = gs + A_BYTES;
     for (int t = 0; t < nkh; ++t) {
-        const bool live = kb + t * BK < p.K;                     // group-uniform
+        const bool live = kof(t) < p.K;                          // group-uniform
         bf16x8 af[2][MI], bfr[2][4];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
