@@ -78,6 +78,8 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing (roofline block)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--no-encoder-step", action="store_true", help="skip the encoder-only (fwd+bwd) timing reported in config")
+    ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
+                    help="vitb16: the headline workload (BASELINE configs[1]/[2]); vitl32: ViT-L, 32 frames (configs[4] in bf16; side measurement)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -99,17 +101,22 @@ def main():
     from mofo_amd.masking_generator import TubeMaskingGenerator, TubeMaskingGenerator_BB
 
     torch.manual_seed(0)           # identical random-init replica on every rank (DDP would broadcast rank 0's)
-    model = mp.pretrain_videomae_base_patch16_224(decoder_depth=4).to(dev)
-    B, N, n_vis = args.batch, 1568, 160
+    if args.model == "vitl32":     # BASELINE configs[4] shapes (bf16 here; its fp8 path is not built): 3136 tokens, 320 visible
+        model = mp.pretrain_videomae_large_patch16_224(decoder_depth=4, num_frames=32).to(dev)
+        B, N, n_vis, grid, step_flop, enc_flop, label = args.batch, 3136, 320, (16, 14, 14), 1104.8e9, 610.0e9, "ViT-L (enc 24x1024, dec 4x512) 32x224x224"
+        args.no_cpu_baseline = True
+    else:
+        model = mp.pretrain_videomae_base_patch16_224(decoder_depth=4).to(dev)
+        B, N, n_vis, grid, step_flop, enc_flop, label = args.batch, 1568, 160, (8, 14, 14), STEP_FLOP_PER_CLIP, ENC_STEP_FLOP_PER_CLIP, "ViT-B (enc 12x768, dec 4x384) 16x224x224"
     clips, mask_u8 = model.input_buffers(B, n_vis)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # seed = base + rank, run_mae_pretraining.py:166
     clips.normal_(generator=gen)
     np.random.seed(rank)
     if args.mask == "tube":
-        mgen = TubeMaskingGenerator((8, 14, 14), 0.9)
+        mgen = TubeMaskingGenerator(grid, 0.9)
         masks = [mgen() for _ in range(B)]
     else:   # per-clip boxes x1,y1 ~ U{0..160}, w,h ~ U{32..160} clipped to 224, replicated over the 16 frames
-        bgen = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)
+        bgen = TubeMaskingGenerator_BB(grid, 0.9, 0.75)
         masks = []
         for _ in range(B):
             x1, y1 = np.random.randint(0, 161, 2)
@@ -177,13 +184,13 @@ def main():
         dt = float(t.item())
     clips_per_s = B * world * args.steps / dt
 
-    out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
+    out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step" if args.model == "vitb16" else "clips/sec (32x3x224x224, mask 90%) ViT-L pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "ViT-B (enc 12x768, dec 4x384) 16x224x224 " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
+           "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
                                   "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "final_loss": round(last, 5),
-                      "step_mfma_frac": round(clips_per_s / world * STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}}
+                      "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4)}}
 
     if prof is not None:
         summ = prof.summary()
@@ -208,7 +215,7 @@ def main():
         # cannot be read from inside the process, so this is the recorded figure, null if the file is absent
         kern = {"gemm_tn_wgrad_f32": "gemm_kernel<1, 1, 5, 1, 4>"}.get(out["roofline"]["kernel"])
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
-        if kern and os.path.exists(tpath):
+        if kern and args.model == "vitb16" and B == 32 and os.path.exists(tpath):   # recorded for the headline workload only
             try:
                 rec = json.load(open(tpath)).get(kern)
                 if rec:
@@ -265,7 +272,7 @@ def main():
                 print(f"  {'_'.join(str(x) for x in k):24s} {v['launches'] // 3:5d} {v['ms'] / 3:8.3f} ms", file=sys.stderr)
             print(f"  sum {sum(v['ms'] for v in es.values()) / 3:.3f} ms", file=sys.stderr)
         out["config"]["encoder_step"] = {"ms": round(enc_ms, 3), "clips_per_s": round(B / enc_ms * 1e3, 1),
-                                         "mfma_frac": round(B / (enc_ms * 1e-3) * ENC_STEP_FLOP_PER_CLIP / PEAK_BF16, 4)}
+                                         "mfma_frac": round(B / (enc_ms * 1e-3) * enc_flop / PEAK_BF16, 4)}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
