@@ -78,6 +78,9 @@ def main():
     ap.add_argument("--no-kernel-events", action="store_true", help="skip the per-kernel HIP-event timing (roofline block)")
     ap.add_argument("--breakdown", action="store_true", help="print the per-kernel-class table to stderr")
     ap.add_argument("--no-encoder-step", action="store_true", help="skip the encoder-only (fwd+bwd) timing reported in config")
+    ap.add_argument("--input", choices=["f32", "uint8"], default="f32",
+                    help="f32: the model's input contract (normalised clips in HBM); uint8: the loader's frame stack [B,H,W,T*3], "
+                         "normalised inside the gather / target kernels (side measurement)")
     ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
                     help="vitb16: the headline workload (BASELINE configs[1]/[2]); vitl32: ViT-L, 32 frames (configs[4] in bf16; side measurement)")
     args = ap.parse_args()
@@ -111,6 +114,9 @@ def main():
     clips, mask_u8 = model.input_buffers(B, n_vis)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)      # seed = base + rank, run_mae_pretraining.py:166
     clips.normal_(generator=gen)
+    if args.input == "uint8":
+        clips, _ = model.input_buffers(B, n_vis, uint8=True)
+        clips.copy_(torch.randint(0, 256, clips.shape, dtype=torch.uint8, device=dev, generator=gen))
     np.random.seed(rank)
     if args.mask == "tube":
         mgen = TubeMaskingGenerator(grid, 0.9)
@@ -189,7 +195,7 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
                                   "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
-                      "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "final_loss": round(last, 5),
+                      "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),
                       "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4)}}
 
     if prof is not None:

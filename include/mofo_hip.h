@@ -136,6 +136,15 @@ int mofo_target_mse(const float* clips, int B, int C, int T, int H, int W, int p
                     const int* msk_idx, int n_msk, const void* pred, int ldp, int normalize, float grad_scale,
                     float* row_loss, float* loss, void* dpred, int lddp, void* target_out_f32, void* stream);
 
+/* ---- ingest fused into the two kernels that read the clip: the same results as mofo_ingest_u8
+ * followed by mofo_patch_gather / mofo_target_mse, bit for bit, computed straight from the uint8 frame stack
+ * [B,H,W,T*3] (transforms.py:346-360) -- the f32 clip is never materialised (C = 3; target: tubelet 2, patch 16). ---- */
+int mofo_patch_gather_u8(const uint8_t* frames, int B, int T, int H, int W, int pt, int p,
+                         const int* tok_idx, int n_tok, void* out_bf16, int ldo, void* stream);
+int mofo_target_mse_u8(const uint8_t* frames, int B, int T, int H, int W, int pt, int p,
+                       const int* msk_idx, int n_msk, const void* pred, int ldp, int normalize, float grad_scale,
+                       float* row_loss, float* loss, void* dpred, int lddp, void* stream);
+
 /* ---- "next" rows, same boundary rules.
  * Reconstruction video of the inference / visualisation script, run_videomae_vis.py:150-180: every token standardised per
  * channel over its 512 pixels (unbiased variance, 1e-6 after the sqrt), masked tokens replaced by the model's predictions

@@ -13,7 +13,29 @@ namespace {
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};  // IMAGENET_DEFAULT_MEAN (engine_for_pretraining.py:45)
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};   // IMAGENET_DEFAULT_STD  (:46)
 
-__global__ __launch_bounds__(256) void target_mse_kernel(const float* __restrict__ clips, int T, int H, int W,
+// pixel sources of the target builder: the f32 clip, or the uint8 frame stack normalised on the fly (see tokens.hip)
+struct PixF32 {
+    const float* clips; int T, H, W;
+    static constexpr bool kBytes = false;
+    __device__ __forceinline__ f32x4 load4(int b, int c, int t, int y, int x0) const {
+        return *(const f32x4*)(clips + ((((size_t)b * 3 + c) * T + t) * H + y) * W + x0);
+    }
+};
+// uint8 frame stack [B][H][W][T*3]: the 6 bytes a tubelet needs of one pixel (2 frames x 3 channels) are contiguous, so
+// ONE bounds-checked 8-byte buffer load per pixel serves all six values (byte p0*3 + c of the returned word).
+struct PixU8 {
+    const uint8_t* frames; int T, H, W;
+    static constexpr bool kBytes = true;
+    __device__ __forceinline__ uint64_t load6(__amdgpu_buffer_rsrc_t rsrc, int b, int tt, int y, int x) const {
+        const uint32_t addr = (uint32_t)(((b * H + y) * W + x) * (T * 3) + tt * 6);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(addr & ~3u), 0, 0);
+        return (((uint64_t)v[1] << 32) | v[0]) >> ((addr & 3u) * 8);
+    }
+    __device__ __forceinline__ f32x4 load4(int, int, int, int, int) const { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+};
+
+template <class PIX>
+__global__ __launch_bounds__(256) void target_mse_kernel(PIX pix, uint32_t frame_bytes,
                                                          const int* __restrict__ msk_idx, int n_msk, int rows,
                                                          const bf16_t* __restrict__ pred, int ldp, int normalize, float gs,
                                                          float* __restrict__ row_loss, bf16_t* __restrict__ dpred, int lddp,
@@ -23,22 +45,44 @@ __global__ __launch_bounds__(256) void target_mse_kernel(const float* __restrict
     if (row >= rows) return;
     const int b = row / n_msk;
     const int tok = msk_idx[row];
-    const int gw = W >> 4, gh = H >> 4;
+    const int gw = pix.W >> 4, gh = pix.H >> 4;
     const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
-    const float* cb = clips + (size_t)b * 3 * T * H * W;
 
+    // the prediction row does not depend on the statistics below: issue its loads first so they fly under the pixel math
+    u32x2 w[2][3];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w[q][i] = *(const u32x2*)(pred + (size_t)row * ldp + (q * 64 + lane) * 12 + 4 * i);
+    // lane -> image row p1 = lane >> 2, pixels (lane & 3) * 4 + k of the 16x16 patch, in both frames q = p0 of the tubelet
     float u[3][2][4];
+    if constexpr (PIX::kBytes) {
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)pix.frames, 0, (int)frame_bytes, 0x00020000);
+        uint64_t px[4];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
+        for (int k = 0; k < 4; ++k) px[k] = pix.load6(rsrc, b, tt, th * 16 + (lane >> 2), tw * 16 + (lane & 3) * 4 + k);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int e = q * 64 + lane;          // float4 index inside the channel's 512 pixels
-            const int seg = e >> 2, qq = e & 3;   // seg = p0*16 + p1
-            const int p0 = seg >> 4, p1 = seg & 15;
-            const float* src = cb + (((size_t)c * T + (tt * 2 + p0)) * H + (th * 16 + p1)) * W + tw * 16 + qq * 4;
-            const f32x4 v = *(const f32x4*)src;
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int k = 0; k < 4; ++k) u[c][q][k] = v[k] * c_std[c] + c_mean[c];
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // ToTorchFormatTensor + GroupNormalize exactly as mofo_ingest_u8, then the target's un-normalise
+                    const float x = ((float)(uint32_t)((px[k] >> (8 * (q * 3 + c))) & 0xff) / 255.0f - c_mean[c]) / c_std[c];
+                    u[c][q][k] = x * c_std[c] + c_mean[c];
+                }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int e = q * 64 + lane;          // float4 index inside the channel's 512 pixels
+                const int seg = e >> 2, qq = e & 3;   // seg = p0*16 + p1
+                const int p0 = seg >> 4, p1 = seg & 15;
+                const f32x4 v = pix.load4(b, c, tt * 2 + p0, th * 16 + p1, tw * 16 + qq * 4);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) u[c][q][k] = v[k] * c_std[c] + c_mean[c];
+            }
         }
     }
     if (normalize) {
@@ -70,17 +114,13 @@ __global__ __launch_bounds__(256) void target_mse_kernel(const float* __restrict
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int e = q * 64 + lane;
-        const bf16_t* pp = pred + (size_t)row * ldp + e * 12;
-        u32x2 w[3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) w[i] = *(const u32x2*)(pp + 4 * i);
         float pv[12];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            pv[4 * i + 0] = bf16lo_to_f32(w[i][0]);
-            pv[4 * i + 1] = bf16hi_to_f32(w[i][0]);
-            pv[4 * i + 2] = bf16lo_to_f32(w[i][1]);
-            pv[4 * i + 3] = bf16hi_to_f32(w[i][1]);
+            pv[4 * i + 0] = bf16lo_to_f32(w[q][i][0]);
+            pv[4 * i + 1] = bf16hi_to_f32(w[q][i][0]);
+            pv[4 * i + 2] = bf16lo_to_f32(w[q][i][1]);
+            pv[4 * i + 3] = bf16hi_to_f32(w[q][i][1]);
         }
         float d[12];
 #pragma unroll
@@ -242,7 +282,7 @@ extern "C" int mofo_target_mse(const float* clips, int B, int C, int T, int H, i
     const double numel = (double)rows * 1536.0;
     const float gs = (float)(2.0 * (double)grad_scale / numel);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(target_mse_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, s, clips, T, H, W, msk_idx, n_msk, rows,
+    hipLaunchKernelGGL(target_mse_kernel<PixF32>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, PixF32{clips, T, H, W}, 0u, msk_idx, n_msk, rows,
                        (const bf16_t*)pred, ldp, normalize, gs, row_loss, (bf16_t*)dpred, lddp, (float*)target_out);
     MOFO_CHECK_LAUNCH("mofo_target_mse");
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, rows, 1.0 / numel, loss);
@@ -264,5 +304,26 @@ extern "C" int mofo_reconstruct(const float* clips, int B, int C, int T, int H, 
     else
         hipLaunchKernelGGL(reconstruct_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, clips, T, H, W, N, msk_idx, n_msk, rows, pred, ldp, rec, masked, ori);
     MOFO_CHECK_LAUNCH("mofo_reconstruct");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_target_mse_u8(const uint8_t* frames, int B, int T, int H, int W, int pt, int p, const int* msk_idx, int n_msk,
+                                  const void* pred, int ldp, int normalize, float grad_scale, float* row_loss, float* loss,
+                                  void* dpred, int lddp, void* stream) {
+    if (!frames || !msk_idx || !pred || !row_loss || !loss) MOFO_FAIL(MOFO_EINVAL, "mofo_target_mse_u8: null pointer");
+    if (pt != 2 || p != 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_target_mse_u8: built for tubelet 2, patch 16 (got %d,%d)", pt, p);
+    if (B <= 0 || n_msk <= 0 || T % 2 || H % 16 || W % 16 || ldp % 4 || ldp < 1536 || (dpred && (lddp % 4 || lddp < 1536)))
+        MOFO_FAIL(MOFO_EINVAL, "mofo_target_mse_u8: bad sizes");
+    const size_t bytes = (size_t)B * H * W * T * 3;
+    if (bytes > 0x7fffffffu) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_target_mse_u8: frame stack of %zu bytes exceeds one 2 GiB buffer descriptor", bytes);
+    const int rows = B * n_msk;
+    const double numel = (double)rows * 1536.0;
+    const float gs = (float)(2.0 * (double)grad_scale / numel);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(target_mse_kernel<PixU8>, dim3(ceil_div(rows, 4)), dim3(256), 0, s, PixU8{frames, T, H, W}, (uint32_t)bytes, msk_idx, n_msk, rows,
+                       (const bf16_t*)pred, ldp, normalize, gs, row_loss, (bf16_t*)dpred, lddp, (float*)nullptr);
+    MOFO_CHECK_LAUNCH("mofo_target_mse_u8");
+    hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(1024), 0, s, (const float*)row_loss, rows, 1.0 / numel, loss);
+    MOFO_CHECK_LAUNCH("mofo_target_mse_u8(reduce)");
     return MOFO_OK;
 }

@@ -47,28 +47,72 @@ __global__ __launch_bounds__(256) void mask_idx_kernel(const uint8_t* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------- tubelet gather
+// Pixel sources.  F32: the model's input contract, clips f32 [B][C][T][H][W] ImageNet-normalised.  U8 (SURVEY.md 8f rank 3,
+// "ingest fused into the K1 / K12 reads"): the reference's Stack() output per clip, uint8 [B][H][W][T*3], normalised on the
+// fly with exactly the operations of mofo_ingest_u8 -- ((u / 255) - mean_c) / std_c -- so the fused path is bit-identical
+// to ingest + the f32 kernels while the f32 clip (4x the bytes) is never written or read.
+__constant__ float c_src_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_src_std[3] = {0.229f, 0.224f, 0.225f};
+struct SrcF32 {
+    const float* clips; int C, T, H, W;
+    __device__ __forceinline__ f32x4 load4(int b, int c, int t, int y, int x0) const {
+        return *(const f32x4*)(clips + ((((size_t)b * C + c) * T + t) * H + y) * W + x0);
+    }
+};
+
+// uint8 source, tubelet 2 x patch 16: one wave per token; lane -> image row p1 = lane >> 2, pixels (lane & 3) * 4 + k.  The 6
+// bytes a tubelet needs of one pixel (2 frames x 3 channels) are contiguous in the frame stack: one bounds-checked 8-byte
+// buffer load per pixel, then six packed stores -- the same (c, p0, p1, p2) columns the f32 kernel writes.
+__global__ __launch_bounds__(256) void patch_gather_u8_kernel(const uint8_t* __restrict__ frames, uint32_t frame_bytes, int T, int H, int W,
+                                                              const int* __restrict__ tok_idx, int n_tok, int rows,
+                                                              bf16_t* __restrict__ out, int ldo) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= rows) return;
+    const int b = row / n_tok;
+    const int tok = tok_idx[row];
+    const int gw = W >> 4, gh = H >> 4;
+    const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)frames, 0, (int)frame_bytes, 0x00020000);
+    uint64_t px[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t addr = (uint32_t)(((b * H + th * 16 + (lane >> 2)) * W + tw * 16 + (lane & 3) * 4 + k) * (T * 3) + tt * 6);
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(addr & ~3u), 0, 0);
+        px[k] = (((uint64_t)v[1] << 32) | v[0]) >> ((addr & 3u) * 8);
+    }
+    bf16_t* orow = out + (size_t)row * ldo;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {            // float4 #(i*64 + lane) of the row: c = i >> 1, p0 = i & 1
+        const int c = i >> 1, p0 = i & 1;
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = ((float)(uint32_t)((px[k] >> (8 * (p0 * 3 + c))) & 0xff) / 255.0f - c_src_mean[c]) / c_src_std[c];
+        u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        *(u32x2*)(orow + (i * 64 + lane) * 4) = pk;
+    }
+}
+
 // one wave per token row; lane e handles float4 #e of the row: row layout (c, p0, p1, p2) so that float4 #e is 16 B
 // of one 16-pixel image row segment (64 B contiguous in the clip).
-__global__ __launch_bounds__(256) void patch_gather_kernel(const float* __restrict__ clips, int C, int T, int H, int W,
-                                                           int pt, int p, const int* __restrict__ tok_idx, int n_tok,
+template <class SRC>
+__global__ __launch_bounds__(256) void patch_gather_kernel(SRC src, int pt, int p, const int* __restrict__ tok_idx, int n_tok,
                                                            int rows, bf16_t* __restrict__ out, int ldo) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int b = row / n_tok;
     const int tok = tok_idx[row];
-    const int gw = W / p, gh = H / p;
+    const int gw = src.W / p, gh = src.H / p;
     const int tw = tok % gw, th = (tok / gw) % gh, tt = tok / (gw * gh);
     const int q4 = p >> 2;            // float4 per segment
-    const int n4 = C * pt * p * q4;   // float4 per row
-    const float* cb = clips + (size_t)b * C * T * H * W;
+    const int n4 = src.C * pt * p * q4;   // float4 per row
     bf16_t* orow = out + (size_t)row * ldo;
     for (int e = lane; e < n4; e += 64) {
         const int seg = e / q4, qq = e - seg * q4;
         const int c = seg / (pt * p), rem = seg - c * (pt * p);
         const int p0 = rem / p, p1 = rem - p0 * p;
-        const float* src = cb + (((size_t)c * T + (tt * pt + p0)) * H + (th * p + p1)) * W + tw * p + qq * 4;
-        const f32x4 v = *(const f32x4*)src;
+        const f32x4 v = src.load4(b, c, tt * pt + p0, th * p + p1, tw * p + qq * 4);
         u32x2 pk = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
         *(u32x2*)(orow + e * 4) = pk;
     }
@@ -219,9 +263,25 @@ extern "C" int mofo_patch_gather(const float* clips, int B, int C, int T, int H,
     if (p % 4 || W % 4 || T % pt || H % p || W % p || ldo % 4 || ldo < C * pt * p * p)
         MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_patch_gather: patch %d / tubelet %d do not tile %dx%dx%d or ldo too small", p, pt, T, H, W);
     const int rows = B * n_tok;
-    hipLaunchKernelGGL(patch_gather_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, clips, C, T, H, W, pt, p,
+    hipLaunchKernelGGL(patch_gather_kernel<SrcF32>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, SrcF32{clips, C, T, H, W}, pt, p,
                        tok_idx, n_tok, rows, (bf16_t*)out, ldo);
     MOFO_CHECK_LAUNCH("mofo_patch_gather");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_patch_gather_u8(const uint8_t* frames, int B, int T, int H, int W, int pt, int p, const int* tok_idx,
+                                    int n_tok, void* out, int ldo, void* stream) {
+    if (!frames || !tok_idx || !out) MOFO_FAIL(MOFO_EINVAL, "mofo_patch_gather_u8: null pointer");
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || pt <= 0 || p <= 0 || n_tok <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_patch_gather_u8: bad sizes");
+    if (pt != 2 || p != 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_patch_gather_u8: built for tubelet 2, patch 16 (got %d,%d)", pt, p);
+    if (T % 2 || H % 16 || W % 16 || ldo % 4 || ldo < 1536)
+        MOFO_FAIL(MOFO_EINVAL, "mofo_patch_gather_u8: 2x16x16 tubelets do not tile %dx%dx%d or ldo too small", T, H, W);
+    const size_t bytes = (size_t)B * H * W * T * 3;
+    if (bytes > 0x7fffffffu) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_patch_gather_u8: frame stack of %zu bytes exceeds one 2 GiB buffer descriptor", bytes);
+    const int rows = B * n_tok;
+    hipLaunchKernelGGL(patch_gather_u8_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, frames, (uint32_t)bytes, T, H, W,
+                       tok_idx, n_tok, rows, (bf16_t*)out, ldo);
+    MOFO_CHECK_LAUNCH("mofo_patch_gather_u8");
     return MOFO_OK;
 }
 

@@ -420,11 +420,18 @@ class PretrainVisionTransformer(_FlatModule):
         rt.set_inputs(w, x, mask)
         return rt, w
 
-    def input_buffers(self, batch_size: int, n_vis: int):
+    def input_buffers(self, batch_size: int, n_vis: int, uint8: bool = False):
         """(clips f32 [B,C,T,H,W], mask u8 [B,N]) persistent device buffers: a loader that writes batches straight into
-        them (or a synthetic generator) skips the per-step staging copy."""
+        them (or a synthetic generator) skips the per-step staging copy.  ``uint8=True`` returns the frame-stack buffer
+        (uint8 [B,H,W,T*3]) of the fused-ingest input path instead of the f32 clip."""
         self.set_visible_tokens(n_vis)
-        w = self.runtime().ws(batch_size, n_vis)
+        rt = self.runtime()
+        w = rt.ws(batch_size, n_vis)
+        if uint8:
+            if getattr(w, "frames_u8", None) is None:
+                d = rt.d
+                w.frames_u8 = torch.empty(batch_size, d.img_size, d.img_size, d.num_frames * 3, dtype=torch.uint8, device=rt.dev)
+            return w.frames_u8, w.mask_u8
         return w.clips, w.mask_u8
 
     def ingest_uint8(self, frames_u8, n_vis: int):
@@ -435,7 +442,7 @@ class PretrainVisionTransformer(_FlatModule):
         clips, _ = self.input_buffers(frames_u8.shape[0], n_vis)
         w = self.runtime().ws(frames_u8.shape[0], n_vis)
         if frames_u8.data_ptr() != getattr(w, "_frames_ptr", None):
-            if not hasattr(w, "frames_u8") or w.frames_u8.shape != frames_u8.shape:
+            if getattr(w, "frames_u8", None) is None or w.frames_u8.shape != frames_u8.shape:
                 w.frames_u8 = torch.empty(frames_u8.shape, dtype=torch.uint8, device=clips.device)
             w.frames_u8.copy_(frames_u8, non_blocking=True)
         ops.ingest_u8(w.frames_u8, clips)
@@ -443,7 +450,9 @@ class PretrainVisionTransformer(_FlatModule):
 
     # -- reference API -------------------------------------------------------------------------------------------
     def forward(self, x, mask):
-        """[B,3,T,H,W] f32, mask bool [B,N] (True = masked) -> [B, N_mask, 1536] f32 predictions, autograd-connected."""
+        """[B,3,T,H,W] f32, mask bool [B,N] (True = masked) -> [B, N_mask, 1536] f32 predictions, autograd-connected.
+        ``x`` may also be the loader's uint8 frame stack [B,H,W,T*3] (transforms.py:346-360): ToTorchFormatTensor +
+        GroupNormalize are then applied inside the kernels that read the pixels, with bit-identical results."""
         rt, w = self._prepare(x, mask)
         return _ModelFn.apply(self._anchor, self, w, False, True, 1.0)
 

@@ -346,6 +346,20 @@ def patch_gather(clips, pt, p, tok_idx, out):
     return out
 
 
+def patch_gather_u8(frames, pt, p, tok_idx, out):
+    """patch_gather straight from the uint8 frame stack [B,H,W,T*3] (normalised on the fly, bit-identical to ingest_u8 + patch_gather)"""
+    _chk(frames, U8, "frames", 4), _chk(tok_idx, I32, "tok_idx", 2), _chk(out, BF16, "out", 2)
+    B, H, W, TC = frames.shape
+    if not frames.is_contiguous() or not tok_idx.is_contiguous() or tok_idx.shape[0] != B or TC % 3:
+        raise ValueError("patch_gather_u8: frames [B,H,W,T*3] / tok_idx must be contiguous with matching batch")
+    n_tok = tok_idx.shape[1]
+    if out.shape != (B * n_tok, 3 * pt * p * p):
+        raise ValueError("patch_gather_u8: out shape")
+    _run("mofo_patch_gather_u8", ("patch_gather",), 3.0 * B * n_tok * 3 * pt * p * p, _p(frames), B, TC // 3, H, W, pt, p, _p(tok_idx), n_tok,
+         _p(out), _ld(out))
+    return out
+
+
 def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
     _chk(mask_token, F32, "mask_token"), _chk(pos, F32, "pos", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(x_full, F32, "x_full", 3)
     B, N, D = x_full.shape
@@ -383,6 +397,25 @@ def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, los
     _run("mofo_target_mse", ("target_mse",), (4.0 + 2.0 + (2.0 if dpred is not None else 0.0)) * B * n_msk * L, _p(clips), B, Cc, T, H, W, pt, p,
          _p(msk_idx), n_msk, _p(pred), _ld(pred), 1 if normalize else 0, grad_scale, _p(row_loss), _p(loss), _p(dpred),
          _ld(dpred) if dpred is not None else 0, _p(target_out))
+    return loss
+
+
+def target_mse_u8(frames, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, loss, dpred=None):
+    """target_mse straight from the uint8 frame stack [B,H,W,T*3] (bit-identical to ingest_u8 + target_mse)"""
+    _chk(frames, U8, "frames", 4), _chk(msk_idx, I32, "msk_idx", 2), _chk(pred, BF16, "pred", 2), _chk(row_loss, F32, "row_loss"), _chk(loss, F32, "loss")
+    B, H, W, TC = frames.shape
+    n_msk = msk_idx.shape[1]
+    L = 3 * pt * p * p
+    if (not frames.is_contiguous() or TC % 3 or not msk_idx.is_contiguous() or msk_idx.shape[0] != B or pred.shape != (B * n_msk, L)
+            or row_loss.numel() < B * n_msk):
+        raise ValueError("target_mse_u8: shape mismatch")
+    if dpred is not None:
+        _chk(dpred, BF16, "dpred", 2)
+        if dpred.shape != pred.shape:
+            raise ValueError("dpred shape")
+    _run("mofo_target_mse_u8", ("target_mse",), (1.0 + 2.0 + (2.0 if dpred is not None else 0.0)) * B * n_msk * L, _p(frames), B, TC // 3, H, W, pt, p,
+         _p(msk_idx), n_msk, _p(pred), _ld(pred), 1 if normalize else 0, grad_scale, _p(row_loss), _p(loss), _p(dpred),
+         _ld(dpred) if dpred is not None else 0)
     return loss
 
 

@@ -2,7 +2,7 @@
 SURVEY.md 8f rank 4.  The script's video decoding (decord) and argument parsing are outside the path; what it computes
 between the model call and the JPEG writer is here:
 
-    out = reconstruct(model, img, bool_masked_pos)      # img [B,3,T,H,W] ImageNet-normalised, mask [B,N] (1/True = masked)
+    out = reconstruct(model, img, bool_masked_pos)      # img [B,3,T,H,W] ImageNet-normalised (or uint8 frames [B,H,W,T*3]), mask [B,N] (1/True = masked)
     out["ori_img"], out["rec_img"], out["mask_img"]     # f32 [B,3,T,H,W] in [0,1] pixel units, on the GPU
     save_frames(out, "/some/dir")                       # ori_img{t}.jpg / rec_img{t}.jpg / mask_img{t}.jpg like :154-181
 
@@ -30,6 +30,8 @@ def reconstruct(model, img, bool_masked_pos):
     rt.forward(w)                                       # predictions bf16 [B*n_msk, 1536], rows in msk_idx order
     raw.check_status(w)
     d = rt.d
+    if w.src_u8:                                        # uint8 frame stack given: the video writer needs the f32 clip once
+        ops.ingest_u8(w.frames_u8, w.clips)
     out = {k: torch.empty_like(w.clips, dtype=F32) for k in ("ori_img", "rec_img", "mask_img")}
     ops.reconstruct(w.clips, d.tubelet, d.patch_size, w.msk_idx, w.pred, out["rec_img"], masked=out["mask_img"], ori=out["ori_img"])
     return out

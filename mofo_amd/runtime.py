@@ -346,8 +346,20 @@ class PretrainRuntime:
     def set_inputs(self, w: NS, videos: torch.Tensor, mask: Optional[torch.Tensor]):
         """H2D / D2D copy of the batch into the persistent input buffers, then mask -> index lists on the device
         (no host sync: the reference's boolean indexing does a nonzero() round trip, modeling_pretrain.py:90)."""
-        if videos.data_ptr() != w.clips.data_ptr():
-            w.clips.copy_(videos, non_blocking=True)
+        if videos.dtype == torch.uint8:
+            # the reference's Stack() output [B,H,W,T*3]: kept as bytes, normalised inside the gather / target kernels
+            d = self.d
+            if tuple(videos.shape) != (w.B, d.img_size, d.img_size, d.num_frames * 3):
+                raise ValueError(f"uint8 input must be frames [B,H,W,T*3] = {(w.B, d.img_size, d.img_size, d.num_frames * 3)}, got {tuple(videos.shape)}")
+            if getattr(w, "frames_u8", None) is None:
+                w.frames_u8 = torch.empty(videos.shape, dtype=torch.uint8, device=self.dev)
+            if videos.data_ptr() != w.frames_u8.data_ptr():
+                w.frames_u8.copy_(videos, non_blocking=True)
+            w.src_u8 = True
+        else:
+            w.src_u8 = False
+            if videos.data_ptr() != w.clips.data_ptr():
+                w.clips.copy_(videos, non_blocking=True)
         if mask is not None:
             w.mask_u8.copy_(mask.reshape(w.B, -1), non_blocking=True)
             ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
@@ -512,7 +524,10 @@ class PretrainRuntime:
     def encoder_forward(self, w: NS):
         """modeling_pretrain.py:83-101 over the VISIBLE tokens only; returns bf16 [B*n_vis, enc_dim] (after encoder.norm)."""
         d, s, p = self.d, self.store, self.enc_prefix
-        ops.patch_gather(w.clips, d.tubelet, d.patch_size, w.vis_idx, w.xp)
+        if getattr(w, "src_u8", False):
+            ops.patch_gather_u8(w.frames_u8, d.tubelet, d.patch_size, w.vis_idx, w.xp)
+        else:
+            ops.patch_gather(w.clips, d.tubelet, d.patch_size, w.vis_idx, w.xp)
         ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, w.xp, s.bview(p + "patch_embed.proj.weight"), w.enc_x0,
                  bias=s.view(p + "patch_embed.proj.bias"), pos=self.pos_enc, row_idx=w.vis_idx.view(-1), rows_in=w.Me, rows_out=w.Me)
         x = w.enc_x0
@@ -602,16 +617,19 @@ class PretrainRuntime:
         return self.decoder_forward(w, x_full, w.n_msk)
 
     def forward(self, w: NS):
-        return self.cached(w, "fwd", lambda: self._forward(w))
+        return self.cached(w, ("fwd", getattr(w, "src_u8", False)), lambda: self._forward(w))
 
     def _loss_forward(self, w, normalize_target, grad_scale):
         d = self.d
-        ops.target_mse(w.clips, d.tubelet, d.patch_size, w.msk_idx, w.pred, normalize_target, grad_scale, w.row_loss, w.loss, w.dpred)
+        if getattr(w, "src_u8", False):
+            ops.target_mse_u8(w.frames_u8, d.tubelet, d.patch_size, w.msk_idx, w.pred, normalize_target, grad_scale, w.row_loss, w.loss, w.dpred)
+        else:
+            ops.target_mse(w.clips, d.tubelet, d.patch_size, w.msk_idx, w.pred, normalize_target, grad_scale, w.row_loss, w.loss, w.dpred)
         return w.loss
 
     def loss_forward(self, w: NS, normalize_target: bool = True, grad_scale: float = 1.0):
         """engine_for_pretraining.py:43-67 fused: target build + MSE + d(loss)/d(pred) in one pass."""
-        return self.cached(w, ("loss", bool(normalize_target), float(grad_scale)),
+        return self.cached(w, ("loss", bool(normalize_target), float(grad_scale), getattr(w, "src_u8", False)),
                            lambda: self._loss_forward(w, normalize_target, grad_scale))
 
     def _backward(self, w: NS):

@@ -414,6 +414,46 @@ def test_ingest_uint8_bit_exact(dev):
         assert torch.equal(clips.cpu(), O.ingest_uint8(frames))
 
 
+@pytest.mark.parametrize("B,T,HW,n_tok", [(2, 16, 224, 160), (3, 16, 32, 4), (1, 32, 64, 100)])
+def test_uint8_fused_reads_are_bit_identical(dev, B, T, HW, n_tok):
+    """tubelet gather and target+MSE reading the uint8 frame stack directly == ingest_u8 followed by the
+    f32 kernels, bit for bit (tokens, row losses, loss, d(loss)/d(pred)); random (non-tube) token subsets"""
+    from mofo_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + T)
+    frames = torch.randint(0, 256, (B, HW, HW, T * 3), dtype=torch.uint8, generator=g).to(dev)
+    N = (T // 2) * (HW // 16) ** 2
+    assert n_tok < N
+    perm = torch.stack([torch.randperm(N, generator=g) for _ in range(B)])
+    vis = perm[:, :n_tok].sort(1).values.int().to(dev).contiguous()
+    msk = perm[:, n_tok:].sort(1).values.int().to(dev).contiguous()
+    n_msk = N - n_tok
+    clips = torch.empty(B, 3, T, HW, HW, dtype=F32, device=dev)
+    ops.ingest_u8(frames, clips)
+    xa = torch.empty(B * n_tok, 1536, dtype=BF16, device=dev)
+    xb = torch.zeros_like(xa)
+    ops.patch_gather(clips, 2, 16, vis, xa)
+    ops.patch_gather_u8(frames, 2, 16, vis, xb)
+    assert torch.equal(xa.view(torch.int16), xb.view(torch.int16))
+    pred = (torch.randn(B * n_msk, 1536, generator=g) * 0.7).to(dev).to(BF16)
+    for normalize in (True, False):
+        res = []
+        for u8 in (False, True):
+            row, loss = torch.zeros(B * n_msk, dtype=F32, device=dev), torch.zeros(1, dtype=F32, device=dev)
+            dp = torch.zeros_like(pred)
+            if u8:
+                ops.target_mse_u8(frames, 2, 16, msk, pred, normalize, 0.5, row, loss, dp)
+            else:
+                ops.target_mse(clips, 2, 16, msk, pred, normalize, 0.5, row, loss, dp)
+            res.append((row, loss, dp))
+        assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+        assert torch.equal(res[0][2].view(torch.int16), res[1][2].view(torch.int16))
+    # argument checks of the new entry points
+    with pytest.raises(ValueError):
+        ops.patch_gather_u8(frames[..., :-1].contiguous(), 2, 16, vis, xb)
+    with pytest.raises(TypeError):
+        ops.target_mse_u8(clips, 2, 16, msk, pred, True, 1.0, row, loss)
+
+
 @pytest.mark.parametrize("cfgname", ["TINY", "VIT_B"])
 def test_patch_gather_and_embed(dev, cfgname):
     from mofo_amd import ops

@@ -455,6 +455,44 @@ def test_finetune_loads_pretraining_checkpoint(dev):
     assert torch.equal(f.state_dict()["blocks.1.mlp.fc2.weight"].cpu(), P["encoder.blocks.1.mlp.fc2.weight"])
 
 
+def test_uint8_frames_train_like_the_ingested_clip(dev):
+    """SURVEY 8f rank 3 end to end: a training step fed the loader's uint8 frame stack [B,H,W,T*3] gives the same
+    loss (bit for bit), gradients and updated weights as the same step fed the clip that mofo_ingest_u8 (= the reference's
+    ToTorchFormatTensor + GroupNormalize, pinned by tests/golden/ingest.npz) makes of it"""
+    from mofo_amd import optim_factory, ops
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool().to(dev)
+    frames = torch.randint(0, 256, (2, cfg.img_size, cfg.img_size, cfg.num_frames * 3), dtype=torch.uint8,
+                           generator=torch.Generator().manual_seed(11)).to(dev)
+    clip = torch.empty(2, 3, cfg.num_frames, cfg.img_size, cfg.img_size, dtype=torch.float32, device=dev)
+    ops.ingest_u8(frames, clip)
+    got = []
+    for x in (clip, frames):
+        model, _ = _build(cfg, "xavier", dev)
+        opt = optim_factory.create_optimizer(_Args, model)
+        losses = []
+        for _ in range(2):
+            opt.zero_grad()
+            loss = model.forward_loss(x, mask)
+            loss.backward()
+            grads = model.runtime().store.grads.clone()
+            opt.step()
+            losses.append(float(loss))
+        model.check_status()
+        got.append((losses, grads, model.runtime().store.params.clone()))
+    # step 1's loss is a deterministic function of the inputs: bit-equal.  Weight gradients accumulate through f32 atomics
+    # (run-to-run order noise), so gradients / weights / the second loss are compared at that noise level.
+    assert got[0][0][0] == got[1][0][0] and np.isfinite(got[0][0]).all()
+    assert got[0][0][1] == pytest.approx(got[1][0][1], rel=1e-5)
+    assert _rel(got[0][1], got[1][1]) < 1e-4 and _rel(got[0][2], got[1][2]) < 1e-6
+    # the reference-API forward accepts the frame stack too, and rejects a wrong layout
+    model, _ = _build(cfg, "xavier", dev)
+    assert torch.equal(model(frames, mask), model(clip, mask))
+    with pytest.raises(ValueError):
+        model(frames.permute(0, 3, 1, 2).contiguous(), mask)
+
+
 def test_bench_json_contract(dev):
     """bench.py prints ONE JSON line with the driver's keys, the roofline block and (N=1) the encoder-only step"""
     import json
