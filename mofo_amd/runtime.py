@@ -436,11 +436,16 @@ class PretrainRuntime:
         self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
+        group = [(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
+                 (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
+        mode = os.environ.get("MOFO_WGRAD_STREAM", "side")
+        if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
+            self._wgrad_group(group)          # same stream: no fork / join events (each costs ~10 us of queue bubble)
+            return
         ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
         ops.use_stream(side)
         ops.host_op(lambda ev=S.ready[k]: side.wait_event(ev))
-        self._wgrad_group([(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
-                           (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))])
+        self._wgrad_group(group)
         ops.host_op(lambda ev=S.done[k]: ev.record(side))
         ops.use_stream(None)
         S.used[k] = True
