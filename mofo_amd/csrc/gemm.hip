@@ -485,8 +485,9 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
 // launched and each walks tiles w, w + grid, w + 2 grid, ...: the first k-stage of the NEXT tile is issued from the last
 // k-iteration of the current one and lands while the epilogue runs.  That needs an epilogue staging area apart from the
 // operand stage: 16 rows x 64 f32 per wave (16 KiB per block, MI passes), 48 KiB of LDS per block -> still 3 blocks / CU.
+// MI 8 (256 x 128 tiles, 64 KiB of LDS, 2 blocks / CU): 25 % fewer L1->LDS bytes and LDS fragment reads per MFMA than MI 4.
 template <int LA, int LB, int EPI, int MI>
-__global__ __launch_bounds__(256, 3) void gemm_persistent_kernel(GemmP p, int total) {
+__global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(GemmP p, int total) {
     static_assert(LA == OPL_ROW, "persistent form is built for the ROW A operand (NT / NN)");
     constexpr int BMT = 32 * MI;
     constexpr int A_BYTES = BMT * 64 * 2;
@@ -731,6 +732,9 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         }
         if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && ((forced < 0 && ksplit_on) || forced == 3)) {
             hipLaunchKernelGGL((gemm_ksplit_kernel<LA, LB, EPI>), dim3(total), dim3(512), 0, s, p, total);
+        } else if (mi == 8) {
+            const dim3 pgrid(total < 512 ? total : 512);
+            hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 8>), pgrid, block, 0, s, p, total);
         } else if (var == 2) {
             const dim3 pgrid(total < 768 ? total : 768);
             if (mi == 2) hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 2>), pgrid, block, 0, s, p, total);
@@ -845,6 +849,22 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
         for (int i = 0; i < count; ++i) t128 += (long long)ceil_div(a[i].M, 128) * ceil_div(a[i].N, BN);
         const char* e = getenv("MOFO_GEMM_MI");
         if (e ? atoi(e) == 2 : t128 < 400) mi = 2;
+        // 256-row tiles (persistent form only: one problem, no split-K / accumulate, not the pos epilogue).  Tile for tile
+        // they are 10-15 % SLOWER than 128-row tiles (2 blocks per CU overlap less than 3: dec.fc1 dgrad 64 -> 74 us), so they
+        // are used only where they repair the grid quantisation: the encoder's fc1 / fc2-dgrad GEMMs are 960 128-row tiles
+        // for 768 resident blocks (1.25 rounds, the second one a quarter full) but 480 256-row tiles for 512 (0.94 of one round):
+        // 36.6 -> 32.8 us and 35.9 -> 33.9 us alone, encoder step 4.99 -> 4.88 ms.  MOFO_GEMM_MI8=0 / 1 turns them off / forces them.
+        static int mi8 = -2;
+        if (mi8 == -2) {
+            const char* e8 = getenv("MOFO_GEMM_MI8");
+            mi8 = e8 ? atoi(e8) : -1;
+        }
+        if (mi != 2 && mi8 != 0 && count == 1 && a[0].splits <= 1 && !a[0].accumulate && a[0].epilogue != MOFO_EPI_POS_F32) {
+            const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, BN);
+            const double eff4 = (double)t128 / (double)(ceil_div((int)t128, 768) * 768);
+            const double eff8 = (double)t256 / (double)(ceil_div((int)t256, 512) * 512);
+            if (mi8 == 1 || eff8 > 1.25 * eff4) mi = 8;
+        }
     }
     for (int i = 0; i < count; ++i) {
         if (a[i].op != a[0].op || a[i].epilogue != a[0].epilogue) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: problems must share op and epilogue");

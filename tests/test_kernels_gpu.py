@@ -34,7 +34,7 @@ def _rel(a, b):
 # ------------------------------------------------------------------------------------------------ GEMM
 # (200, 136, 1600): ragged M and N with an ODD number of 64-wide k-stages through the in-block split-K kernel (K >= 1536, few tiles)
 GEMM_SHAPES = [(128, 128, 64), (256, 384, 128), (320, 2304, 768), (77, 192, 128), (16, 64, 64), (640, 768, 3072), (1000, 1536, 384),
-               (200, 136, 1600)]
+               (200, 136, 1600), (5000, 3064, 128)]   # the last one takes the 256-row-tile form (960 vs 480 tiles), ragged on both axes
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -93,7 +93,7 @@ def test_gemm_nt_pos_rowmap(dev):
     assert torch.all(got[:, nv:] == -7.0)      # rows outside the map untouched
 
 
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 768, 2304), (77, 128, 192), (640, 3072, 768), (50, 64, 256), (200, 136, 1600)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 768, 2304), (77, 128, 192), (640, 3072, 768), (50, 64, 256), (200, 136, 1600), (5000, 3064, 128)])
 def test_gemm_nn_dgrad(dev, M, N, K):
     from mofo_amd import ops
     A = _rand((M, K), dev, 1)            # dY [M, Nf]
