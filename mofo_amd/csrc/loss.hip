@@ -150,8 +150,15 @@ __global__ __launch_bounds__(256) void target_mse_kernel(PIX pix, uint32_t frame
 __global__ __launch_bounds__(1024) void loss_reduce_kernel(const float* __restrict__ row_loss, int rows, double inv_numel,
                                                            float* __restrict__ loss) {
     __shared__ double red[16];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < rows; i += 1024) s += (double)row_loss[i];
+    // four independent partial sums per thread: the loads of a thread's 44 rows (B = 32) are all in flight at once
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int i = threadIdx.x;
+    for (; i + 3 * 1024 < rows; i += 4 * 1024) {
+        const float a = row_loss[i], b = row_loss[i + 1024], c = row_loss[i + 2048], d = row_loss[i + 3072];
+        s0 += (double)a; s1 += (double)b; s2 += (double)c; s3 += (double)d;
+    }
+    for (; i < rows; i += 1024) s0 += (double)row_loss[i];
+    double s = (s0 + s1) + (s2 + s3);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
