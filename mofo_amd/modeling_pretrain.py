@@ -476,7 +476,9 @@ def _finish(model, pretrained, kwargs):
 
 
 def _drop(kwargs):
-    kw = dict(kwargs)
+    """factory kwargs -> constructor kwargs; ``img_size`` defaults to the factories' 224 but may be overridden (smaller
+    clips in tests / the launcher's --input_size), which the reference's fixed keyword does not allow"""
+    kw = {"img_size": 224, **kwargs}
     kw.pop("init_ckpt", None)
     kw.pop("drop_block_rate", None)
     return kw
@@ -484,7 +486,7 @@ def _drop(kwargs):
 
 def pretrain_mae_small_patch16_224(pretrained=False, **kwargs):
     """modeling_pretrain.py:268-290"""
-    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=384, encoder_depth=12, encoder_num_heads=6,
+    model = PretrainVisionTransformer(patch_size=16, encoder_embed_dim=384, encoder_depth=12, encoder_num_heads=6,
                                       encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=192, decoder_num_heads=3,
                                       mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
     return _finish(model, pretrained, kwargs)
@@ -492,7 +494,7 @@ def pretrain_mae_small_patch16_224(pretrained=False, **kwargs):
 
 def pretrain_videomae_base_patch16_224(pretrained=False, **kwargs):
     """modeling_pretrain.py:292-314"""
-    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=768, encoder_depth=12, encoder_num_heads=12,
+    model = PretrainVisionTransformer(patch_size=16, encoder_embed_dim=768, encoder_depth=12, encoder_num_heads=12,
                                       encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=384, decoder_num_heads=6,
                                       mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
     return _finish(model, pretrained, kwargs)
@@ -500,7 +502,7 @@ def pretrain_videomae_base_patch16_224(pretrained=False, **kwargs):
 
 def pretrain_videomae_large_patch16_224(pretrained=False, **kwargs):
     """modeling_pretrain.py:316-338"""
-    model = PretrainVisionTransformer(img_size=224, patch_size=16, encoder_embed_dim=1024, encoder_depth=24, encoder_num_heads=16,
+    model = PretrainVisionTransformer(patch_size=16, encoder_embed_dim=1024, encoder_depth=24, encoder_num_heads=16,
                                       encoder_num_classes=0, decoder_num_classes=1536, decoder_embed_dim=512, decoder_num_heads=8,
                                       mlp_ratio=4, qkv_bias=True, norm_layer=partial(nn.LayerNorm, eps=1e-6), **_drop(kwargs))
     return _finish(model, pretrained, kwargs)

@@ -246,3 +246,34 @@ def test_finetune_model_schema_and_checkpoint_mapping():
             ft.vit_base_patch16_224(num_classes=400, **kw)
     feat = ft.vit_base_patch16_224_feature_ext(num_classes=400)
     assert type(feat).__name__ == "VisionTransformer_feat_ext"
+
+
+def test_launcher_flags_and_synthetic_dataset_contract():
+    """mofo_amd.run_mae_pretraining: the reference's flag names / defaults for what the path reads (run_mae_pretraining.py:22-131)
+    and a dataset whose items have VideoMAE.__getitem__'s layout (kinetics.py:492-495), normalised exactly like the
+    reference's transforms (oracle.ingest_uint8 is pinned to them by tests/golden/ingest.npz)"""
+    from mofo_amd import run_mae_pretraining as R
+    from oracle import pretrain_oracle as O
+    a = R.get_args([])
+    ref_defaults = dict(batch_size=12, epochs=800, save_ckpt_freq=50, model="pretrain_videomae_base_patch16_224", decoder_depth=4,
+                        mask_type="tube", mask_ratio=0.9, input_size=224, drop_path=0.0, normlize_target=True, opt="adamw",
+                        opt_eps=1e-8, opt_betas=(0.9, 0.95), clip_grad=None, weight_decay=0.05, weight_decay_end=None, lr=1.5e-4,
+                        warmup_lr=1e-6, min_lr=1e-5, warmup_epochs=40, warmup_steps=-1, num_frames=16, sampling_rate=2, seed=0,
+                        resume="", auto_resume=True, start_epoch=0, pin_mem=True, world_size=1, local_rank=-1, dist_url="env://")
+    for k, v in ref_defaults.items():
+        assert getattr(a, k) == v, k
+    b = R.get_args(["--no_auto_resume", "--no_pin_mem", "--normlize_target", "False", "--opt_betas", "0.8", "0.9", "--mask_ratio_BB", "0.75"])
+    assert (b.auto_resume, b.pin_mem, b.normlize_target, b.opt_betas, b.mask_ratio_BB) == (False, False, False, [0.8, 0.9], 0.75)
+    np.random.seed(4)
+    ds = R.SyntheticClips(5, 8, 64, (4, 4, 4), 0.9, seed=3)
+    clip, mask = ds[2]
+    assert clip.shape == (3, 8, 64, 64) and clip.dtype == torch.float32 and clip.is_contiguous()
+    assert mask.shape == (64,) and mask.dtype == np.float64 and mask.sum() == 4 * 14
+    assert torch.equal(clip, ds[2][0]) and not torch.equal(clip, ds[3][0])                # deterministic per index
+    raw = R.SyntheticClips(5, 8, 64, (4, 4, 4), 0.9, uint8_frames=True, seed=3)[2][0]
+    assert raw.shape == (64, 64, 24) and raw.dtype == torch.uint8
+    assert torch.equal(O.ingest_uint8(raw[None])[0], clip)                                # same pixels, reference normalisation
+    clip_b, boxes, mask_b = R.SyntheticClips(5, 8, 64, (4, 4, 4), 0.9, mask_ratio_BB=0.75, seed=3)[1]
+    assert boxes.shape == (8, 4) and mask_b.sum() == 4 * 14 and torch.equal(boxes[0], boxes[7])
+    batch = next(iter(torch.utils.data.DataLoader(ds, batch_size=2)))                     # default collate, as the reference uses
+    assert batch[0].shape == (2, 3, 8, 64, 64) and batch[1].shape == (2, 64) and batch[1].dtype == torch.float64

@@ -528,6 +528,34 @@ def test_uint8_frames_train_like_the_ingested_clip(dev):
         model(frames.permute(0, 3, 1, 2).contiguous(), mask)
 
 
+def test_launcher_trains_checkpoints_and_resumes(dev, tmp_path, capsys):
+    """mofo_amd.run_mae_pretraining end to end on a small geometry: the loss falls on the synthetic clips, log.txt and the
+    checkpoints appear as the reference writes them, a second invocation auto-resumes at the next epoch; then one epoch
+    each through the uint8-frames input and the motion-box (BB) engine"""
+    import json
+    from mofo_amd import run_mae_pretraining as R
+    out = str(tmp_path / "run")
+    common = ["--model", "pretrain_mae_small_patch16_224", "--input_size", "64", "--num_frames", "8", "--batch_size", "4",
+              "--synthetic_clips", "16", "--warmup_epochs", "1", "--lr", "2e-2", "--save_ckpt_freq", "2", "--output_dir", out]
+    hist = R.main(common + ["--epochs", "6"])
+    assert [h["epoch"] for h in hist] == list(range(6))
+    losses = [h["train_loss"] for h in hist]
+    assert all(b < a for a, b in zip(losses, losses[1:])) and losses[-1] < 0.9 * losses[0]   # 24 small steps: 1.20 -> 1.01
+    assert all(np.isfinite(h["train_grad_norm"]) and h["train_loss_scale"] == 1.0 for h in hist)
+    lines = [json.loads(l) for l in open(os.path.join(out, "log.txt"))]
+    assert len(lines) == 6 and set(lines[0]) == {"train_loss", "train_loss_scale", "train_lr", "train_min_lr", "train_weight_decay",
+                                                 "train_grad_norm", "epoch", "n_parameters"}
+    assert sorted(f for f in os.listdir(out) if f.endswith(".pth")) == ["checkpoint-1.pth", "checkpoint-3.pth", "checkpoint-5.pth"]
+    hist2 = R.main(common + ["--epochs", "7"])                            # auto-resume from checkpoint-5
+    assert [h["epoch"] for h in hist2] == [6]
+    assert "Auto resume checkpoint" in capsys.readouterr().out
+    h8 = R.main(common[:-2] + ["--epochs", "1", "--uint8_frames"])
+    hf = R.main(common[:-2] + ["--epochs", "1"])
+    assert h8[0]["train_loss"] == pytest.approx(hf[0]["train_loss"], rel=1e-4)   # same pixels, same seed: same epoch
+    hb = R.main(common[:-2] + ["--epochs", "1", "--mask_ratio_BB", "0.75"])
+    assert np.isfinite(hb[0]["train_loss"])
+
+
 def test_bench_json_contract(dev):
     """bench.py prints ONE JSON line with the driver's keys, the roofline block and (N=1) the encoder-only step"""
     import json
