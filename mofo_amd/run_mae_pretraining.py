@@ -52,6 +52,7 @@ _FLAGS = [
     # not in the reference: the dataset plug
     ("synthetic_clips", 0, int, "length of the synthetic dataset (drifting sinusoid textures, deterministic per index)"),
     ("uint8_frames", False, "store_true", "dataset yields uint8 [H,W,T*3] frame stacks; normalisation runs on the GPU"),
+    ("prefetch", True, "flag", "copy batch i+1 to the GPU on a side stream while step i runs (utils.DevicePrefetcher)"),
 ]
 
 
@@ -175,6 +176,8 @@ class Pretrainer:
                                                   pin_memory=args.pin_mem and self.device.type == "cuda", drop_last=True,
                                                   worker_init_fn=seed_worker)
 
+        if args.prefetch and self.device.type == "cuda":
+            self.loader = utils.DevicePrefetcher(self.loader, self.device)
         model.to(self.device)
         n_vis = args.window_size[0] * (args.window_size[1] * args.window_size[2] - int(args.mask_ratio * args.window_size[1] * args.window_size[2]))
         model.set_visible_tokens(n_vis)                                   # known on the host: no device sync on the first batch
