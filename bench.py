@@ -91,12 +91,19 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # one rank per GPU; MOFO_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (RCCL refuses that)
+    backend = os.environ.get("MOFO_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
     force_dp = os.environ.get("MOFO_FORCE_DP") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or force_dp:
-        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+        else:
+            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
 
     from mofo_amd import _lib, optim_factory, utils
     from mofo_amd import modeling_pretrain as mp

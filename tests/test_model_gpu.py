@@ -331,6 +331,53 @@ def test_gradient_sync_on_one_rank_rccl(dev):
         os.environ.pop("MOFO_FORCE_DP", None)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_share_one_gpu_like_the_multi_gpu_job(dev, tmp_path, world):
+    """The N > 1 job rehearsed on the one GPU of this box: ``world`` processes under torch.distributed.run (tests/_dp_worker.py),
+    gloo instead of RCCL (which refuses two ranks on one device), otherwise the production path -- flat parameter
+    broadcast from rank 0, per-bucket asynchronous all-reduce issued from inside the replayed backward, join, fused AdamW.
+    Ranks start from DIFFERENT weights and train on their own shard: afterwards all ranks hold the same parameters, and
+    they equal a single process training on the whole global batch (mean of shard means = global mean)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = str(tmp_path / "dp.json")
+    env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29540 + world), os.path.join(root, "tests", "_dp_worker.py"), out],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    res = json.load(open(out))
+    assert res["world"] == world and res["segments"] >= 3
+    assert max(res["rank_param_diff"]) == 0.0                         # replicas stay bit-identical (same reduced gradients, same update)
+    assert res["grads_vs_single_process"] < 2e-2                      # all-reduced shard gradients = the whole-batch gradient (bf16 noise)
+    assert res["params_vs_single_process"] < 2e-2                     # ... and so is the trajectory (Adam amplifies noise on tiny gradients)
+    mean_losses = np.mean(np.array(res["losses"]), axis=0)            # mean of the ranks' shard losses = loss of the whole batch
+    np.testing.assert_allclose(mean_losses, res["ref_losses"], rtol=2e-3)
+    assert res["ref_losses"][-1] < res["ref_losses"][0]
+
+
+def test_bench_two_ranks_rehearsal(dev):
+    """bench.py as the driver launches it for N = 2 (torch.distributed.run, one rank per process), rehearsed on one GPU
+    through MOFO_DIST_BACKEND=gloo: one JSON line from rank 0 with the whole-job rate"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {**os.environ, "MOFO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29547", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
+    assert out["value"] == pytest.approx(8 / out["ms_per_step"] * 1e3, rel=1e-3) and math.isfinite(out["config"]["final_loss"])
+    assert "cpu_baseline" not in out and "roofline" in out
+
+
 def test_vit_large_32_frames_parity(dev):
     """BASELINE config 4's architecture (ViT-L, 32x224x224 -> 3136 tokens, 320 visible) in bf16 against the oracle.
     The reference hard-wires 16 frames; tables are extended with the same sincos formula."""
