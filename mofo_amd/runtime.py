@@ -207,6 +207,9 @@ def _wsplits(P, Q, R):
     return int(max(1, min(-(-256 // tiles), 16, R // 1024)))
 
 
+_GRAPHS = os.environ.get("MOFO_GRAPH", "0") == "1"
+
+
 class PretrainRuntime:
     """Forward / backward of encoder, bridge (encoder_to_decoder + token assembly), decoder and the fused loss."""
 
@@ -522,7 +525,26 @@ class PretrainRuntime:
                 _lib.RECORDER = None
             cache[tag] = (rec, out)
             return out
+        if _GRAPHS and self.segment_hook is None:
+            return self._graph_replay(cache, tag, lst)
         ops.replay(lst[0])
+        return lst[1]
+
+    def _graph_replay(self, cache, tag, lst):
+        """MOFO_GRAPH=1: the recorded launch list as a hipGraph (captured on its second use, launched as ONE graph from then
+        on).  The lists are capture-clean by construction -- fixed pointers, no allocation, no host sync; the side-stream
+        sections fork and join through events inside the list, which is the capture-legal pattern.  Not used under data
+        parallelism (the bucket all-reduces are issued from inside the list).  Off by default: the host already runs a full
+        step ahead of the device, so graph launch changes the step time only by the start-of-step gap."""
+        graphs = cache.setdefault("_graphs", {})
+        g = graphs.get(tag)
+        if g is None:
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                ops.replay(lst[0])
+            graphs[tag] = g
+        g.replay()
         return lst[1]
 
     # ------------------------------------------------------------------ encoder

@@ -625,3 +625,9 @@ def test_bench_json_contract(dev):
     assert out["roofline"]["frac"] == pytest.approx(out["roofline"]["achieved"] / out["roofline"]["peak"], rel=1e-2)
     assert "workload" in out["config"] and "encoder_step" in out["config"]
     assert math.isfinite(out["config"]["final_loss"])
+    # the same run with the recorded launch lists replayed as hipGraphs (MOFO_GRAPH=1, off by default: slower on this stack)
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "3", "--batch", "4", "--no-cpu-baseline",
+                         "--no-kernel-events", "--no-encoder-step"], capture_output=True, text=True, timeout=600, env={**os.environ, "MOFO_GRAPH": "1"})
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert out2["config"]["final_loss"] == pytest.approx(out["config"]["final_loss"], rel=1e-4)
