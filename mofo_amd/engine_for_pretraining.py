@@ -16,12 +16,12 @@ from . import utils
 
 def _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_norm, normlize_target, it, lr_schedule_values,
                  wd_schedule_values):
-    if lr_schedule_values is not None or wd_schedule_values is not None:
-        for param_group in optimizer.param_groups:
-            if lr_schedule_values is not None:
-                param_group["lr"] = lr_schedule_values[it] * param_group["lr_scale"]
-            if wd_schedule_values is not None and param_group["weight_decay"] > 0:
-                param_group["weight_decay"] = wd_schedule_values[it]
+    # per-step schedule tables (engine_for_pretraining.py:31-37): lr scaled per group, weight decay only where it is on
+    for group in optimizer.param_groups:
+        if lr_schedule_values is not None:
+            group["lr"] = lr_schedule_values[it] * group["lr_scale"]
+        if wd_schedule_values is not None and group["weight_decay"] > 0:
+            group["weight_decay"] = wd_schedule_values[it]
     raw = getattr(model, "module", model)
     # mask arrives from the loader as float64 [B, N] (1 = masked); the visible count is known on the host -> no device sync
     if not bool_masked_pos.is_cuda and raw._n_vis_cache is None:
@@ -45,50 +45,40 @@ def _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_nor
     return loss_value, grad_norm, loss_scale_value
 
 
+def _group_summary(optimizer):
+    """what the reference logs about the optimizer each step (engine_for_pretraining.py:184-196): the largest and smallest
+    group lr, and the weight decay of the (last) decayed group"""
+    rates = [g["lr"] for g in optimizer.param_groups]
+    decays = [g["weight_decay"] for g in optimizer.param_groups if g["weight_decay"] > 0]
+    return min([10.] + rates), max([0.] + rates), (decays[-1] if decays else None)
+
+
 def _train(model, data_loader, optimizer, device, epoch, loss_scaler, max_norm, patch_size, normlize_target, log_writer,
            lr_scheduler, start_steps, lr_schedule_values, wd_schedule_values, has_bbox):
     model.train()
     if patch_size != 16:
         raise NotImplementedError("the fused target/loss kernel is built for patch_size 16")
-    metric_logger = utils.MetricLogger(delimiter="  ")
-    metric_logger.add_meter('lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
-    metric_logger.add_meter('min_lr', utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
-    header = 'Epoch: [{}]'.format(epoch)
-    for step, batch in enumerate(metric_logger.log_every(data_loader, 10, header)):
-        it = start_steps + step
-        if has_bbox:
-            videos, _bbox, bool_masked_pos = batch
-        else:
-            videos, bool_masked_pos = batch
-        loss_value, grad_norm, loss_scale_value = _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_norm,
-                                                               normlize_target, it, lr_schedule_values, wd_schedule_values)
-        metric_logger.update(loss=loss_value)
-        metric_logger.update(loss_scale=loss_scale_value)
-        min_lr, max_lr = 10., 0.
-        for group in optimizer.param_groups:
-            min_lr = min(min_lr, group["lr"])
-            max_lr = max(max_lr, group["lr"])
-        metric_logger.update(lr=max_lr)
-        metric_logger.update(min_lr=min_lr)
-        weight_decay_value = None
-        for group in optimizer.param_groups:
-            if group["weight_decay"] > 0:
-                weight_decay_value = group["weight_decay"]
-        metric_logger.update(weight_decay=weight_decay_value)
-        metric_logger.update(grad_norm=grad_norm)
+    meters = utils.MetricLogger(delimiter="  ")
+    for name in ("lr", "min_lr"):                      # shown as the current value, not a windowed median
+        meters.add_meter(name, utils.SmoothedValue(window_size=1, fmt='{value:.6f}'))
+    for step, batch in enumerate(meters.log_every(data_loader, 10, f"Epoch: [{epoch}]")):
+        videos, bool_masked_pos = batch[0], batch[-1]   # (videos, mask) or, for the motion-box loader, (videos, boxes, mask)
+        loss_value, grad_norm, scale = _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_norm, normlize_target,
+                                                    start_steps + step, lr_schedule_values, wd_schedule_values)
+        lo, hi, decay = _group_summary(optimizer)
+        # meter order = the reference's print order: loss, loss_scale, lr, min_lr, weight_decay, grad_norm
+        record = {"loss": loss_value, "loss_scale": scale, "lr": hi, "min_lr": lo, "weight_decay": decay, "grad_norm": grad_norm}
+        for name, value in record.items():
+            meters.update(**{name: value})
         if log_writer is not None:
-            log_writer.update(loss=loss_value, head="loss")
-            log_writer.update(loss_scale=loss_scale_value, head="opt")
-            log_writer.update(lr=max_lr, head="opt")
-            log_writer.update(min_lr=min_lr, head="opt")
-            log_writer.update(weight_decay=weight_decay_value, head="opt")
-            log_writer.update(grad_norm=grad_norm, head="opt")
+            for name, value in record.items():
+                log_writer.update(head="loss" if name == "loss" else "opt", **{name: value})
             log_writer.set_step()
         if lr_scheduler is not None:
             lr_scheduler.step_update(start_steps + step)
-    metric_logger.synchronize_between_processes()
-    print("Averaged stats:", metric_logger)
-    return {k: meter.global_avg for k, meter in metric_logger.meters.items()}
+    meters.synchronize_between_processes()
+    print("Averaged stats:", meters)
+    return {name: m.global_avg for name, m in meters.meters.items()}
 
 
 def train_one_epoch(model: torch.nn.Module, data_loader: Iterable, optimizer: torch.optim.Optimizer,
