@@ -230,19 +230,19 @@ def get_grad_norm_(parameters, norm_type: float = 2.0) -> torch.Tensor:
 
 
 def cosine_scheduler(base_value, final_value, epochs, niter_per_ep, warmup_epochs=0, start_warmup_value=0, warmup_steps=-1):
-    """utils.py:391-408"""
-    warmup_schedule = np.array([])
-    warmup_iters = warmup_epochs * niter_per_ep
-    if warmup_steps > 0:
-        warmup_iters = warmup_steps
-    print("Set warmup steps = %d" % warmup_iters)
-    if warmup_epochs > 0:
-        warmup_schedule = np.linspace(start_warmup_value, base_value, warmup_iters)
-    n = epochs * niter_per_ep - warmup_iters
-    schedule = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * i / n)) for i in range(n)])
-    schedule = np.concatenate((warmup_schedule, schedule))
-    assert len(schedule) == epochs * niter_per_ep
-    return schedule
+    """utils.py:391-408: one value per optimizer step -- linear warm-up from ``start_warmup_value`` to ``base_value`` (over
+    ``warmup_steps`` if given, else ``warmup_epochs`` epochs; only when ``warmup_epochs > 0``, as in the reference), then half
+    a cosine from ``base_value`` to ``final_value``.  float64 numpy, the reference's own rounding."""
+    total = epochs * niter_per_ep
+    n_warm = warmup_steps if warmup_steps > 0 else warmup_epochs * niter_per_ep
+    print("Set warmup steps = %d" % n_warm)
+    ramp = np.linspace(start_warmup_value, base_value, n_warm) if warmup_epochs > 0 else np.array([])
+    n_cos = total - n_warm
+    tail = np.array([final_value + 0.5 * (base_value - final_value) * (1 + math.cos(math.pi * k / n_cos)) for k in range(n_cos)])
+    table = np.concatenate((ramp, tail))
+    if len(table) != total:
+        raise AssertionError(f"schedule has {len(table)} entries for {total} steps (warmup_steps without warmup_epochs?)")
+    return table
 
 
 # ----------------------------------------------------------------------------------------------- checkpoints
@@ -267,13 +267,15 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
         if best >= 0:
             args.resume = os.path.join(args.output_dir, 'checkpoint-%d.pth' % best)
         print("Auto resume checkpoint: %s" % getattr(args, "resume", ""))
-    if getattr(args, "resume", ""):
-        checkpoint = torch.load(args.resume, map_location='cpu', weights_only=False)
-        model_without_ddp.load_state_dict(checkpoint['model'])
-        print("Resume checkpoint %s" % args.resume)
-        if 'optimizer' in checkpoint and 'epoch' in checkpoint:
-            optimizer.load_state_dict(checkpoint['optimizer'])
-            args.start_epoch = checkpoint['epoch'] + 1
-            if 'scaler' in checkpoint:
-                loss_scaler.load_state_dict(checkpoint['scaler'])
-            print("With optim & sched!")
+    path = getattr(args, "resume", "")
+    if not path:
+        return
+    state = torch.load(path, map_location='cpu', weights_only=False)
+    model_without_ddp.load_state_dict(state['model'])
+    print("Resume checkpoint %s" % path)
+    if {'optimizer', 'epoch'} <= set(state):            # a full training checkpoint: continue after its epoch
+        optimizer.load_state_dict(state['optimizer'])
+        args.start_epoch = state['epoch'] + 1
+        if 'scaler' in state:
+            loss_scaler.load_state_dict(state['scaler'])
+        print("With optim & sched!")
