@@ -18,6 +18,9 @@ import os
 import sys
 import time
 
+# the host driver supports dmabuf IPC only: RCCL's peer mappings need this before HIP initialises (already exported on the boxes)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 

@@ -22,6 +22,8 @@ import os
 import random
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL's peer mappings (multi-process runs)
+
 import numpy as np
 import torch
 
