@@ -165,11 +165,16 @@ int mofo_token_mean_norm(const float* x, int ldx, int B, int N, int D, const flo
  * (lr1,wd1).  partial f32 [>= 1024] scratch.  If max_norm > 0 the gradient is scaled by min(1, max_norm/(norm+1e-6))
  * with norm read from grad_norm[0] on the device (no host sync).  When no clipping is wanted the norm is not needed
  * BEFORE the update: pass norm_partial (f32 [>= 2048] scratch) and norm_out and mofo_adamw leaves the global L2 norm of
- * the gradients it has just read in norm_out[0] (saves mofo_sumsq's extra pass over them); both NULL otherwise. ---- */
+ * the gradients it has just read in norm_out[0] (saves mofo_sumsq's extra pass over them); both NULL otherwise.
+ * Range by range (data parallelism: a range of the flat buffers is updated as soon as ITS all-reduce has landed, while
+ * later ranges are still on the wire): call mofo_adamw on sub-ranges (offsets multiples of 1024) with norm_partial pointing
+ * at consecutive slices of mofo_adamw_blocks(n_range) floats and norm_out NULL, then mofo_norm_finalize over all slices. ---- */
 int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, void* stream);
 int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream);
+int mofo_adamw_blocks(long long n);
+int mofo_norm_finalize(const float* partial, int count, float* out_norm, void* stream);
 int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
 
 #ifdef __cplusplus

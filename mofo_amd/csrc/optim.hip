@@ -121,12 +121,21 @@ extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
                        chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
-                       (norm_partial && norm_out) ? norm_partial : nullptr);
+                       norm_partial);
     MOFO_CHECK_LAUNCH("mofo_adamw");
     if (norm_partial && norm_out) {     // global gradient L2 norm as a by-product of the pass that reads the gradients anyway
         hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)norm_partial, stream_blocks(n / 4), norm_out);
         MOFO_CHECK_LAUNCH("mofo_adamw(norm)");
     }
+    return MOFO_OK;
+}
+
+extern "C" int mofo_adamw_blocks(long long n) { return n > 0 ? stream_blocks(n / 4) : 0; }
+
+extern "C" int mofo_norm_finalize(const float* partial, int count, float* out_norm, void* stream) {
+    if (!partial || !out_norm || count < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_norm_finalize: bad arguments");
+    hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, partial, count, out_norm);
+    MOFO_CHECK_LAUNCH("mofo_norm_finalize");
     return MOFO_OK;
 }
 

@@ -44,6 +44,17 @@ class GradSync:
         self.handles.clear()
         self.launched.clear()
 
+    def drain(self):
+        """hand the outstanding exchanges over range by range: ``[(lo, hi, wait), ...]`` in the order they were issued
+        (= the order they complete on RCCL's stream), or None when this backward issued none / not for the whole buffer.
+        The optimizer waits for a range right before it updates it (optim_factory.FusedAdamW.step(ranges=...))."""
+        total = self.model.runtime().store.grads.numel()
+        if not self.enabled or len(self.handles) != len(self.launched) or sum(hi - lo for _, lo, hi in self.launched) != total:
+            return None
+        out = [(lo, hi, h.wait) for (_, lo, hi), h in zip(self.launched, self.handles)]
+        self.handles, self.launched = [], []
+        return out
+
 
 class DataParallel(torch.nn.Module):
     """Thin stand-in for torch DDP at run_mae_pretraining.py:225-227: exposes ``.module``, broadcasts rank 0's parameters

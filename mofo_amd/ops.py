@@ -460,6 +460,19 @@ def sumsq_norm(g, partial, out_norm):
     return out_norm
 
 
+def adamw_blocks(n):
+    """block partials one adamw launch over n elements writes into norm_partial"""
+    return int(_lib.load().mofo_adamw_blocks(int(n)))
+
+
+def norm_finalize(partial, count, out_norm):
+    """out_norm[0] = sqrt(sum(partial[:count])): closes a range-by-range adamw sequence"""
+    _chk(partial, F32, "partial", 1), _chk(out_norm, F32, "out_norm")
+    if count < 1 or partial.numel() < count:
+        raise ValueError("norm_finalize: count")
+    _run("mofo_norm_finalize", ("norm_fin",), 4.0 * count, _p(partial), int(count), _p(out_norm))
+
+
 def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0,
           norm_partial=None, norm_out=None):
     """``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out"""
@@ -473,12 +486,14 @@ def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps
         _chk(p_bf16, BF16, "p_bf16", 1)
         if p_bf16.numel() != n:
             raise ValueError("p_bf16 length")
-    if (norm_partial is None) != (norm_out is None):
-        raise ValueError("adamw: norm_partial and norm_out go together")
+    if norm_out is not None and norm_partial is None:
+        raise ValueError("adamw: norm_out needs the norm_partial scratch")
+    if norm_partial is not None:     # with norm_out None the block partials are left for norm_finalize (range-by-range update)
+        _chk(norm_partial, F32, "norm_partial", 1)
+        if norm_partial.numel() < adamw_blocks(n):
+            raise ValueError("norm_partial must hold adamw_blocks(n) floats (at most 2048)")
     if norm_out is not None:
-        _chk(norm_partial, F32, "norm_partial", 1), _chk(norm_out, F32, "norm_out")
-        if norm_partial.numel() < 2048:
-            raise ValueError("norm_partial must hold 2048 floats")
+        _chk(norm_out, F32, "norm_out")
     _run("mofo_adamw", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
          lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out))
 

@@ -72,9 +72,12 @@ class FusedAdamW(torch.optim.Optimizer):
         return self.param_groups[0]
 
     @torch.no_grad()
-    def step(self, closure=None, grad_norm=None, max_norm=0.0, norm_out=None):
+    def step(self, closure=None, grad_norm=None, max_norm=0.0, norm_out=None, ranges=None):
         """``norm_out`` (device f32 [1], only without clipping): the update pass also leaves the global gradient L2 norm
-        there -- the norm is reported, not needed before the update, so the gradients are read once instead of twice"""
+        there -- the norm is reported, not needed before the update, so the gradients are read once instead of twice.
+        ``ranges`` (data parallelism, un-clipped step): iterable of ``(lo, hi, wait)`` tiling the flat buffers in the order
+        their gradient all-reduces were issued; ``wait()`` makes the stream wait for that range's exchange, then the range
+        is updated -- the HBM-bound update of the early ranges runs while the last range is still on the wire."""
         if closure is not None:
             raise NotImplementedError("closure")
         rt, st = self._bind()
@@ -89,10 +92,31 @@ class FusedAdamW(torch.optim.Optimizer):
             if getattr(self, "_norm_partial", None) is None or self._norm_partial.device != st.params.device:
                 self._norm_partial = torch.empty(2048, dtype=torch.float32, device=st.params.device)
             partial = self._norm_partial
-        ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group,
-                  float(g0["lr"]), float(g0["weight_decay"]), float(g1["lr"]), float(g1["weight_decay"]),
-                  float(b1), float(b2), float(g0["eps"]), self._step, grad_norm=grad_norm,
-                  max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out)
+        hyper = (float(g0["lr"]), float(g0["weight_decay"]), float(g1["lr"]), float(g1["weight_decay"]), float(b1), float(b2), float(g0["eps"]), self._step)
+        if ranges is not None:
+            if max_norm or grad_norm is not None:
+                raise ValueError("range-by-range update is for the un-clipped step")
+            ranges = list(ranges)
+            slots = sum(ops.adamw_blocks(hi - lo) for lo, hi, _ in ranges)
+            if getattr(self, "_range_partial", None) is None or self._range_partial.numel() < slots:
+                self._range_partial = torch.empty(max(slots, 1), dtype=torch.float32, device=st.params.device)
+            covered, slot = 0, 0
+            for lo, hi, wait in ranges:
+                if lo % 1024 or hi % 1024 or hi <= lo:
+                    raise ValueError(f"range [{lo}, {hi}) is not a 1024-aligned slice of the flat buffers")
+                wait()
+                nb = ops.adamw_blocks(hi - lo)
+                ops.adamw(st.params[lo:hi], st.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], st.shadow[lo:hi],
+                          st.chunk_group[lo // 1024:hi // 1024], *hyper, norm_partial=self._range_partial[slot:slot + nb] if norm_out is not None else None)
+                slot += nb
+                covered += hi - lo
+            if covered != st.params.numel():
+                raise RuntimeError(f"ranges cover {covered} of {st.params.numel()} elements")
+            if norm_out is not None:
+                ops.norm_finalize(self._range_partial, slot, norm_out)
+        else:
+            ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group, *hyper, grad_norm=grad_norm,
+                      max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out)
         st.mark_shadow_fresh()
 
     # checkpoint.  Written in torch.optim.AdamW's own state_dict layout -- state[i] = {'step','exp_avg','exp_avg_sq'} with i

@@ -199,13 +199,17 @@ class NativeScalerWithGradNormCount:
         if model is None:
             raise TypeError("use mofo_amd.optim_factory.create_optimizer: the fused step works on the model's flat buffers")
         sync = getattr(model, "_grad_sync", None)
-        if sync is not None:
-            sync.finish()              # data-parallel all-reduces launched during backward
         rt = model.runtime()
         if not clip_grad:
-            # utils.py:376-388: the norm is only REPORTED here, so the AdamW pass computes it from the gradients it reads anyway
-            optimizer.step(norm_out=rt.norm_out)
+            # utils.py:376-388: the norm is only REPORTED here, so the AdamW pass computes it from the gradients it reads anyway;
+            # under data parallelism each gradient range is updated as soon as ITS all-reduce has landed
+            ranges = sync.drain() if sync is not None else None
+            if sync is not None and ranges is None:
+                sync.finish()
+            optimizer.step(norm_out=rt.norm_out, ranges=ranges)
             return rt.norm_out
+        if sync is not None:
+            sync.finish()              # clipping needs the global norm of the fully exchanged gradients first
         norm = rt.grad_norm()                  # utils.py:376-388, device scalar; needed before the update for clip_grad_norm_
         optimizer.step(grad_norm=norm, max_norm=clip_grad)
         return norm

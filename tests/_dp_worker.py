@@ -46,14 +46,15 @@ def train(model, wrapped, x, mask, steps):
     grads = model.runtime().store.grads.detach().clone()
     opt.step()
     losses.append(float(loss.detach()))
+    norms = []
     for _ in range(steps - 1):
         loss = wrapped.forward_loss(x, mask)
         opt.zero_grad()
-        scaler(loss, opt, clip_grad=None)
+        norms.append(float(scaler(loss, opt, clip_grad=None)))    # under DP: range-by-range AdamW, norm from its block partials
         losses.append(float(loss.detach()))
     model.check_status()
     torch.cuda.synchronize()
-    return losses, model.runtime().store.params.detach().clone(), grads
+    return losses, model.runtime().store.params.detach().clone(), grads, norms
 
 
 def main():
@@ -76,7 +77,7 @@ def main():
     wrapped = DataParallel(model)
     assert wrapped.sync.enabled and wrapped.world_size == world
     n_seg = len(model.runtime().segments)
-    losses, params, grads = train(model, wrapped, x_all[sl].to(dev), mask_all[sl].to(dev), steps)
+    losses, params, grads, norms = train(model, wrapped, x_all[sl].to(dev), mask_all[sl].to(dev), steps)
     assert not wrapped.sync.handles
     params = params.cpu()
     gathered = [torch.empty_like(params) for _ in range(world)] if rank == 0 else None
@@ -86,11 +87,11 @@ def main():
     if rank == 0:
         torch.manual_seed(100)                 # the single-process run over the WHOLE batch, from rank 0's initial weights
         ref_model = build(cfg, dev)
-        ref_losses, ref_params, ref_grads = train(ref_model, ref_model, x_all.to(dev), mask_all.to(dev), steps)
+        ref_losses, ref_params, ref_grads, ref_norms = train(ref_model, ref_model, x_all.to(dev), mask_all.to(dev), steps)
         rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
         json.dump({"world": world, "segments": n_seg, "losses": all_losses, "ref_losses": ref_losses,
                    "rank_param_diff": [rel(g, gathered[0]) for g in gathered], "params_vs_single_process": rel(gathered[0], ref_params),
-                   "grads_vs_single_process": rel(grads, ref_grads)}, open(out_path, "w"))
+                   "grads_vs_single_process": rel(grads, ref_grads), "norms": norms, "ref_norms": ref_norms}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 
