@@ -133,13 +133,6 @@ class SyntheticClips(torch.utils.data.Dataset):
         return clip, self.masked_position_generator()
 
 
-def seed_worker(worker_id):
-    """utils.py:196-199: numpy / random of a DataLoader worker follow torch's per-worker seed (the masks come from numpy)"""
-    s = torch.initial_seed() % 2 ** 32
-    np.random.seed(s)
-    random.seed(s)
-
-
 class Pretrainer:
     """everything run_mae_pretraining.py's ``main`` sets up, as an object: ``Pretrainer(args).fit()``"""
 
@@ -176,7 +169,7 @@ class Pretrainer:
         self.sampler = torch.utils.data.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=True)
         self.loader = torch.utils.data.DataLoader(dataset, sampler=self.sampler, batch_size=args.batch_size, num_workers=args.num_workers,
                                                   pin_memory=args.pin_mem and self.device.type == "cuda", drop_last=True,
-                                                  worker_init_fn=seed_worker)
+                                                  worker_init_fn=utils.seed_worker)
 
         if args.prefetch and self.device.type == "cuda":
             self.loader = utils.DevicePrefetcher(self.loader, self.device)

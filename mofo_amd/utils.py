@@ -142,6 +142,15 @@ def init_distributed_mode(args):
     dist.barrier()
 
 
+def seed_worker(worker_id):
+    """utils.py:196-199: numpy / random of a DataLoader worker follow torch's per-worker seed (the mask generators draw
+    from numpy's global RNG inside the workers)"""
+    import random
+    s = torch.initial_seed() % 2 ** 32
+    np.random.seed(s)
+    random.seed(s)
+
+
 # ----------------------------------------------------------------------------------------------- input pipeline
 class DevicePrefetcher:
     """Wrap a DataLoader so that batch i+1's host->device copy of the CLIP tensor runs on its own HIP stream while step i
