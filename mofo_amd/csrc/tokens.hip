@@ -180,9 +180,11 @@ __global__ __launch_bounds__(256) void assemble_bwd_kernel(const void* __restric
 // frames: the reference's Stack() output per clip, uint8 [B][H][W][T*3] (frame-major, then r,g,b) -- transforms.py:346-360;
 // clips: f32 [B][3][T][H][W] = ((u / 255) - mean_c) / std_c, i.e. ToTorchFormatTensor(div=True) (transforms.py:363-382),
 // GroupNormalize (datasets.py:12-14) and the view/transpose of kinetics.py:492-493, with the same IEEE fp32 operations.
-// One thread per pixel column w: 16-B loads of its T*3 bytes, stores coalesced over w in each (c,t) plane.
+// One thread per pixel column w: VEC-byte loads of its T*3 bytes (16 when T*3 is a multiple of 16 -- 16 / 32 frames --, else
+// 8 / 4 / 1), stores coalesced over w in each (c,t) plane.
 __constant__ float c_in_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_in_std[3] = {0.229f, 0.224f, 0.225f};
+template <int VEC>
 __global__ __launch_bounds__(256) void ingest_u8_kernel(const uint8_t* __restrict__ frames, int T, int H, int W,
                                                         float* __restrict__ clips) {
     const int w = blockIdx.x * 256 + threadIdx.x;
@@ -192,15 +194,24 @@ __global__ __launch_bounds__(256) void ingest_u8_kernel(const uint8_t* __restric
     const uint8_t* src = frames + (((size_t)b * H + h) * W + w) * nb;
     float* dst = clips + (size_t)b * 3 * T * H * W + (size_t)h * W + w;
     const size_t plane = (size_t)H * W;
-    for (int k = 0; k < nb; k += 16) {
-        const u32x4 v = *(const u32x4*)(src + k);
+    for (int k = 0; k < nb; k += VEC) {
+        uint32_t v[VEC >= 4 ? VEC / 4 : 1];
+        if constexpr (VEC == 16) {
+            const u32x4 q = *(const u32x4*)(src + k);
+            v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else if constexpr (VEC == 8) {
+            const u32x2 q = *(const u32x2*)(src + k);
+            v[0] = q[0]; v[1] = q[1];
+        } else if constexpr (VEC == 4) {
+            v[0] = *(const uint32_t*)(src + k);
+        } else {
+            v[0] = src[k];
+        }
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            if (k + e < nb) {
-                const int idx = k + e, t = idx / 3, c = idx - 3 * t;
-                const float u = (float)((v[e >> 2] >> (8 * (e & 3))) & 0xffu);
-                dst[((size_t)c * T + t) * plane] = (u / 255.0f - c_in_mean[c]) / c_in_std[c];
-            }
+        for (int e = 0; e < VEC; ++e) {
+            const int idx = k + e, t = idx / 3, c = idx - 3 * t;
+            const float u = (float)((v[e >> 2] >> (8 * (e & 3))) & 0xffu);
+            dst[((size_t)c * T + t) * plane] = (u / 255.0f - c_in_mean[c]) / c_in_std[c];
         }
     }
 }
@@ -240,9 +251,14 @@ __global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restri
 
 extern "C" int mofo_ingest_u8(const uint8_t* frames, int B, int T, int H, int W, float* clips, void* stream) {
     if (!frames || !clips) MOFO_FAIL(MOFO_EINVAL, "mofo_ingest_u8: null pointer");
-    if (B <= 0 || T <= 0 || H <= 0 || W <= 0 || (T * 3) % 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_ingest_u8: T*3 must be a multiple of 16 (T=%d)", T);
+    if (B <= 0 || T <= 0 || H <= 0 || W <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_ingest_u8: bad sizes");
     if (H > 65535 || B > 65535) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_ingest_u8: grid too large");
-    hipLaunchKernelGGL(ingest_u8_kernel, dim3(ceil_div(W, 256), H, B), dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
+    const dim3 grid(ceil_div(W, 256), H, B);
+    const int nb = T * 3;
+    if (nb % 16 == 0) hipLaunchKernelGGL(ingest_u8_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
+    else if (nb % 8 == 0) hipLaunchKernelGGL(ingest_u8_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
+    else if (nb % 4 == 0) hipLaunchKernelGGL(ingest_u8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
+    else hipLaunchKernelGGL(ingest_u8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
     MOFO_CHECK_LAUNCH("mofo_ingest_u8");
     return MOFO_OK;
 }

@@ -10,8 +10,10 @@ The model forward (tube-masked encoder + decoder) is the pretraining forward; th
 patches with each patch's own mean / std and the re-assembly into a video is one HIP kernel (``mofo_reconstruct``) that
 reads the clip once -- the reference materialises four [B,1568,512,3] intermediates (:158-172).
 """
+import argparse
 import os
 
+import numpy as np
 import torch
 
 from . import ops
@@ -23,7 +25,7 @@ def reconstruct(model, img, bool_masked_pos):
     """run_videomae_vis.py:137-180.  ``model``: mofo_amd PretrainVisionTransformer on the GPU.  Returns a dict of f32
     [B,3,T,H,W] tensors: ``ori_img`` (:152), ``rec_img`` (:169-173, before the writer's clamp) and ``mask_img`` (:180)."""
     raw = getattr(model, "module", model)
-    if img.dim() == 4:          # the script's single clip [3,T,H,W] (:141)
+    if img.dim() == (3 if img.dtype == torch.uint8 else 4):   # a single clip: [3,T,H,W] (:141) or one uint8 frame stack [H,W,T*3]
         img, bool_masked_pos = img.unsqueeze(0), bool_masked_pos.reshape(1, -1)
     rt, w = raw._prepare(img, bool_masked_pos.flatten(1))
     rt.store.refresh_shadow()
@@ -47,3 +49,53 @@ def save_frames(out, save_path, clip=0):
     for name, t in (("ori_img", out["ori_img"][clip]), ("rec_img", out["rec_img"][clip].clamp(0, 0.996)), ("mask_img", out["mask_img"][clip])):
         for i, im in enumerate(frames(t)):
             im.save(os.path.join(save_path, f"{name}{i}.jpg"))
+
+
+def get_args(argv=None):
+    """the reference script's arguments (run_videomae_vis.py:48-72); ``img_path`` is a ``.npy`` of decoded frames here"""
+    ap = argparse.ArgumentParser("VideoMAE / MOFO reconstruction on MI355X (mofo_amd)")
+    ap.add_argument("img_path", type=str, help="frames as .npy: uint8 [T, H, W, 3] already cropped to input_size (video decoding is outside this package)")
+    ap.add_argument("save_path", type=str, help="directory for ori_img*.jpg / rec_img*.jpg / mask_img*.jpg")
+    ap.add_argument("model_path", type=str, help="checkpoint written by utils.save_model (or by the reference)")
+    ap.add_argument("--mask_type", default="tube", choices=["tube"], type=str)
+    ap.add_argument("--num_frames", type=int, default=16)
+    ap.add_argument("--decoder_depth", default=4, type=int)
+    ap.add_argument("--input_size", default=224, type=int)
+    ap.add_argument("--device", default="cuda:0")
+    ap.add_argument("--mask_ratio", default=0.75, type=float)
+    ap.add_argument("--model", default="pretrain_videomae_base_patch16_224", type=str)
+    ap.add_argument("--seed", default=None, type=int, help="numpy seed for the mask draw")
+    return ap.parse_args(argv)
+
+
+def main(argv=None):
+    """run_videomae_vis.py:75-181 without the decord reader: frames -> (clip, tube mask) -> model -> three JPEG series"""
+    from .masking_generator import TubeMaskingGenerator
+    from .modeling_pretrain import create_model
+    args = get_args(argv)
+    dev = torch.device(args.device)
+    model = create_model(args.model, pretrained=False, drop_path_rate=0.0, drop_block_rate=None, decoder_depth=args.decoder_depth,
+                         **({"num_frames": args.num_frames} if args.num_frames != 16 else {}),
+                         **({"img_size": args.input_size} if args.input_size != 224 else {}))
+    patch = model.encoder.patch_embed.patch_size
+    window = (args.num_frames // 2, args.input_size // patch[0], args.input_size // patch[1])
+    state = torch.load(args.model_path, map_location="cpu", weights_only=False)
+    model.load_state_dict(state["model"] if "model" in state else state)
+    model.to(dev).eval()
+    frames = np.load(args.img_path)
+    want = (args.num_frames, args.input_size, args.input_size, 3)
+    if frames.dtype != np.uint8 or frames.shape != want:
+        raise SystemExit(f"{args.img_path}: need uint8 frames {want}, got {frames.dtype} {frames.shape}")
+    # the loader's Stack() layout [H, W, T*3]; ToTorchFormatTensor + GroupNormalize run inside the kernels
+    stack = torch.from_numpy(np.ascontiguousarray(frames.transpose(1, 2, 0, 3).reshape(args.input_size, args.input_size, -1)))
+    if args.seed is not None:
+        np.random.seed(args.seed)
+    mask = torch.from_numpy(TubeMaskingGenerator(window, args.mask_ratio)()).bool()
+    out = reconstruct(model, stack.unsqueeze(0).to(dev), mask.unsqueeze(0).to(dev))
+    save_frames(out, args.save_path)
+    print(f"wrote {3 * args.num_frames} frames to {args.save_path}")
+    return out
+
+
+if __name__ == "__main__":
+    main()

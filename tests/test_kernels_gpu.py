@@ -407,7 +407,7 @@ def test_ingest_uint8_bit_exact(dev):
     """stacked uint8 frames -> normalised f32 clip, bit-exact with the reference's CPU transform arithmetic (oracle)"""
     from mofo_amd import ops
     from oracle import pretrain_oracle as O
-    for B, T, H, W in [(2, 16, 224, 224), (1, 32, 32, 48), (3, 16, 17, 33)]:
+    for B, T, H, W in [(2, 16, 224, 224), (1, 32, 32, 48), (3, 16, 17, 33), (2, 8, 64, 64), (1, 4, 20, 36), (2, 3, 16, 16)]:   # 16- / 8- / 4- / 1-byte loads
         frames = torch.randint(0, 256, (B, H, W, T * 3), dtype=torch.uint8, generator=torch.Generator().manual_seed(B))
         clips = torch.empty(B, 3, T, H, W, dtype=F32, device=dev)
         ops.ingest_u8(frames.to(dev), clips)

@@ -576,6 +576,32 @@ def test_uint8_frames_train_like_the_ingested_clip(dev):
         model(frames.permute(0, 3, 1, 2).contiguous(), mask)
 
 
+def test_reconstruction_cli_from_checkpoint(dev, tmp_path):
+    """python -m mofo_amd.run_videomae_vis: checkpoint + decoded frames (.npy) -> the three JPEG series; the tensors it
+    writes equal reconstruct() on the clip normalised the reference's way"""
+    from mofo_amd import modeling_pretrain as mp, run_videomae_vis as V
+    from oracle import pretrain_oracle as O
+    torch.manual_seed(3)
+    model = mp.create_model("pretrain_mae_small_patch16_224", decoder_depth=2, num_frames=8, img_size=64)
+    ckpt, npy, out_dir = str(tmp_path / "ck.pth"), str(tmp_path / "frames.npy"), str(tmp_path / "vis")
+    torch.save({"model": model.state_dict()}, ckpt)
+    frames = np.random.RandomState(0).randint(0, 256, (8, 64, 64, 3)).astype(np.uint8)
+    np.save(npy, frames)
+    out = V.main([npy, out_dir, ckpt, "--model", "pretrain_mae_small_patch16_224", "--decoder_depth", "2", "--num_frames", "8",
+                  "--input_size", "64", "--mask_ratio", "0.75", "--seed", "7"])
+    names = sorted(os.listdir(out_dir))
+    assert len(names) == 24 and names[0] == "mask_img0.jpg" and "rec_img7.jpg" in names and "ori_img3.jpg" in names
+    stack = torch.from_numpy(np.ascontiguousarray(frames.transpose(1, 2, 0, 3).reshape(64, 64, 24)))
+    clip = O.ingest_uint8(stack[None]).to(dev)
+    np.random.seed(7)
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    mask = torch.from_numpy(TubeMaskingGenerator((4, 4, 4), 0.75)()).bool()[None].to(dev)
+    ref = V.reconstruct(model.to(dev), clip, mask)
+    for k in ("ori_img", "rec_img", "mask_img"):
+        assert torch.equal(out[k], ref[k]), k
+    assert float((ref["ori_img"][0].permute(1, 2, 3, 0).cpu() * 255 - torch.from_numpy(frames).float()).abs().max()) < 1e-2
+
+
 def test_launcher_trains_checkpoints_and_resumes(dev, tmp_path, capsys):
     """mofo_amd.run_mae_pretraining end to end on a small geometry: the loss falls on the synthetic clips, log.txt and the
     checkpoints appear as the reference writes them, a second invocation auto-resumes at the next epoch; then one epoch
