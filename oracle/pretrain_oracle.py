@@ -467,9 +467,17 @@ def adamw_step(P: Dict[str, torch.Tensor], G: Dict[str, torch.Tensor], st: AdamW
         p.addcdiv_(st.m[name], denom, value=-lr / c1)
 
 
+def clip_grads(grads: Dict[str, torch.Tensor], total_norm: torch.Tensor, max_norm: float) -> None:
+    """torch.nn.utils.clip_grad_norm_ as the reference's scaler applies it (utils.py:359): every gradient times
+    min(1, max_norm / (total_norm + 1e-6)), in place"""
+    coef = torch.clamp(max_norm / (total_norm + 1e-6), max=1.0)
+    for g in grads.values():
+        g.mul_(coef)
+
+
 def train_step(x: torch.Tensor, mask: torch.Tensor, P: Dict[str, torch.Tensor], cfg: OracleConfig,
                st: Optional[AdamWState] = None, lr: float = 1.5e-4, weight_decay: float = 0.05,
-               normalize_target: bool = True):
+               normalize_target: bool = True, clip_grad: Optional[float] = None):
     """One step of engine_for_pretraining.py:39-69,172-176 on CPU fp32 (the PNG dump at :74-166 and the
     two CUDA-only lines :177,:179 are not part of the arithmetic).  Returns (loss, grad_norm, grads)."""
     leaves = {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
@@ -480,6 +488,9 @@ def train_step(x: torch.Tensor, mask: torch.Tensor, P: Dict[str, torch.Tensor], 
     loss.backward()
     grads = {k: v.grad for k, v in leaves.items()}
     gn = grad_norm(grads)
+    if clip_grad:
+        with torch.no_grad():
+            clip_grads(grads, gn, clip_grad)       # the returned norm stays the one BEFORE clipping, as the reference reports it
     if st is not None:
         with torch.no_grad():
             adamw_step(P, grads, st, lr, weight_decay)

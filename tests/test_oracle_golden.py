@@ -210,3 +210,20 @@ def test_finetune_forward_matches_reference(tag, ncls, nb):
         logits = O.finetune_forward(x, P, cfg)
     np.testing.assert_allclose(feat.numpy(), g["features"], rtol=2e-4, atol=2e-5)
     np.testing.assert_allclose(logits.numpy(), g["logits"], rtol=2e-4, atol=2e-5)
+
+
+def test_clipped_steps_match_reference_scaler():
+    """three steps with clip_grad=0.1 (active: the norm is 0.126): losses, norms reported before clipping and parameters
+    afterwards against the reference's scaler + clip_grad_norm_ + create_optimizer (tests/golden/tiny_clip.npz)"""
+    g = _load("tiny_clip.npz")
+    cfg = O.TINY
+    P = O.keyed_params(cfg, "xavier")
+    x = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(_load("masks.npz")["tube_tiny_s10"]).bool()
+    st = O.AdamWState()
+    out = [O.train_step(x, mask, P, cfg, st, clip_grad=float(g["clip_grad"]))[:2] for _ in range(3)]
+    np.testing.assert_allclose([o[0] for o in out], g["losses"], rtol=1e-5)
+    np.testing.assert_allclose([o[1] for o in out], g["norms"], rtol=1e-4)
+    assert all(n > float(g["clip_grad"]) for n in g["norms"])          # the clip really bites
+    for i, n in enumerate(str(s) for s in g["names"]):
+        assert float(P[n].double().norm()) == pytest.approx(g["param_stats_after3"][i, 0], rel=1e-5, abs=1e-7), n

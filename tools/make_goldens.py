@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-vitb", action="store_true")
     ap.add_argument("--only-next", action="store_true", help="only the fixtures of the SURVEY 8f 'next' rows (vis.npz, finetune_*.npz)")
+    ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -137,6 +138,9 @@ def main():
 
     if args.only_next:
         make_next(args, ref_mg, ref_mf, O)
+        return
+    if args.only_clip:
+        make_clip(args, ref_mp, ref_of, ref_utils, O)
         return
 
     # ------------------------------------------------------------------ F1 masks
@@ -369,6 +373,45 @@ def main():
                         names=np.array(names), grad_stats=gstat, grad_head=ghead,
                         out_slice=out0[:, :6, :48].numpy(), out_sum=np.array(out0.double().sum().item()))
     print("vitb_bb: loss", losses, "gn", norms)
+
+
+def make_clip(args, ref_mp, ref_of, ref_utils, O):
+    """tiny_clip.npz: three steps of the tiny config through the reference's NativeScalerWithGradNormCount with
+    clip_grad=0.1 (utils.py:353-367: unscale -> torch.nn.utils.clip_grad_norm_ -> optimizer.step; the value returned is the
+    norm BEFORE clipping) and the reference's create_optimizer: losses, returned norms, parameter statistics afterwards."""
+    import contextlib
+    import io
+    from functools import partial as _partial
+
+    class OptArgs:
+        opt, lr, weight_decay, opt_eps, opt_betas, momentum = "adamw", 1.5e-4, 0.05, 1e-8, (0.9, 0.95), 0.9
+
+    cfg = O.TINY
+    P = O.keyed_params(cfg, "xavier")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref_mp.PretrainVisionTransformer(
+            img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+            encoder_num_heads=cfg.enc_heads, encoder_num_classes=0, decoder_num_classes=cfg.patch_dim, decoder_embed_dim=cfg.dec_dim,
+            decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+            norm_layer=_partial(torch.nn.LayerNorm, eps=1e-6))
+    model.load_state_dict(P, strict=True)
+    videos = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(np.load(os.path.join(args.out, "masks.npz"))["tube_tiny_s10"]).bool()
+    labels = O.build_targets(videos, mask, cfg)          # pinned on ViT-B by engine_vitb.npz
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = ref_of.create_optimizer(OptArgs, model)
+    scaler = ref_utils.NativeScalerWithGradNormCount()
+    losses, norms = [], []
+    for _ in range(3):
+        loss = torch.nn.MSELoss()(model(videos, mask), labels)
+        opt.zero_grad()
+        norm = scaler(loss, opt, clip_grad=0.1, parameters=model.parameters())
+        losses.append(loss.item())
+        norms.append(float(norm))
+    names, pstat, phead = tensor_stats(dict(model.named_parameters()))
+    np.savez_compressed(os.path.join(args.out, "tiny_clip.npz"), clip_grad=np.array(0.1), losses=np.array(losses), norms=np.array(norms),
+                        names=np.array(names), param_stats_after3=pstat, param_head_after3=phead)
+    print("tiny_clip: losses", losses, "norms (before clipping)", norms)
 
 
 def make_next(args, ref_mg, ref_mf, O):
