@@ -144,6 +144,42 @@ def test_tiny_clipped_training_steps(dev):
     assert all(n > float(g["clip_grad"]) for n in g["norms"])
 
 
+def test_gradient_accumulation_over_two_batches(dev):
+    """two backward passes without zero_grad in between (the scaler's update_grad=False, utils.py:353-367): the second one
+    ADDS to the flat gradient buffer (atomic / accumulate epilogues instead of plain stores); the sum equals the oracle's
+    two gradients, and a zero_grad afterwards returns to overwrite mode"""
+    from mofo_amd import optim_factory, utils
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(img_size=64, enc_dim=192, enc_depth=3, enc_heads=3, dec_dim=128, dec_depth=2, dec_heads=2)
+    model, P = _build(cfg, "xavier", dev)
+    opt = optim_factory.create_optimizer(_Args, model)
+    scaler = utils.NativeScalerWithGradNormCount()
+    x = O.keyed_clips(4, cfg)
+    np.random.seed(9)
+    gen = TubeMaskingGenerator(cfg.grid, 0.75)
+    mask = torch.from_numpy(np.stack([gen() for _ in range(4)])).bool()
+    halves = [slice(0, 2), slice(2, 4)]
+    ref = [O.train_step(x[h], mask[h], P, cfg)[2] for h in halves]
+    opt.zero_grad()
+    for h in halves:
+        loss = model.forward_loss(x[h].to(dev), mask[h].to(dev))
+        assert scaler(loss, opt, update_grad=False) is None
+    got = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+    total = float(torch.sqrt(sum((ref[0][n] + ref[1][n]).double().pow(2).sum() for n in ref[0])))
+    for n in ref[0]:
+        want = ref[0][n] + ref[1][n]
+        assert _rel(got[n], want) < 5e-2 or float(want.norm()) < 2e-4 * total, n
+    assert float(model.runtime().grad_norm()) == pytest.approx(total, rel=2e-2)
+    # back to a fresh step: zero_grad, one backward, gradients of the second half alone
+    opt.zero_grad()
+    loss = model.forward_loss(x[halves[1]].to(dev), mask[halves[1]].to(dev))
+    loss.backward()
+    for n in ref[1]:
+        assert _rel(model.get_parameter(n).grad, ref[1][n]) < 5e-2 or float(ref[1][n].norm()) < 2e-4 * total, n
+    model.check_status()
+
+
 def _vitb_inputs(dev, which):
     from oracle import pretrain_oracle as O
     m = np.load(os.path.join(G, "masks.npz"))
