@@ -34,6 +34,12 @@ class GradSync:
         self.launched.append((idx, lo, hi))
         if not self.enabled:
             return
+        if self.model.runtime()._accumulate:
+            # SUM of (already exchanged earlier gradients + this rank's new ones) would count the earlier ones world times
+            # (torch DDP averages, which leaves values that are equal on all ranks unchanged); the pretraining loop never
+            # accumulates (engine_for_pretraining.py:172-176 always steps), so this is refused rather than half-supported
+            raise NotImplementedError("gradient accumulation (backward without zero_grad) under data parallelism: call "
+                                      "optimizer.zero_grad() before every backward")
         g = self.model.runtime().store.grads[lo:hi]
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
