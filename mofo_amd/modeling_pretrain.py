@@ -116,6 +116,19 @@ def _check_heads(dim, heads):
 
 
 # ----------------------------------------------------------------------------------------- autograd glue
+def _stamp(ctx, w):
+    """The runtime keeps ONE set of saved activations per batch size: a backward through an output whose activations a
+    later forward has overwritten would silently use the wrong ones -- every forward stamps the workspace, backward checks."""
+    w.generation = getattr(w, "generation", 0) + 1
+    ctx.generation = w.generation
+
+
+def _check_stamp(ctx, w):
+    if ctx.generation != w.generation:
+        raise RuntimeError("backward through a stale forward: a later forward of the same batch size has overwritten the saved "
+                           "activations (mofo_amd keeps one set per batch size; run backward before the next forward)")
+
+
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, w):
@@ -123,11 +136,13 @@ class _EncoderFn(torch.autograd.Function):
         rt.store.refresh_shadow()
         out = rt.encoder_forward(w)
         ctx.mod, ctx.w = mod, w
+        _stamp(ctx, w)
         return out.view(w.B, w.n_vis, -1).float()
 
     @staticmethod
     def backward(ctx, g):
         mod, w = ctx.mod, ctx.w
+        _check_stamp(ctx, w)
         mod._ensure_grads()
         w.d_encout.copy_(g.reshape(w.Me, -1))
         mod._rt.begin_backward()
@@ -143,11 +158,13 @@ class _DecoderFn(torch.autograd.Function):
         w.x_full.copy_(x)
         pred = rt.decoder_forward(w, w.x_full, n_ret)
         ctx.mod, ctx.w, ctx.n_ret = mod, w, n_ret
+        _stamp(ctx, w)
         return pred.view(w.B, n_ret, -1).float()
 
     @staticmethod
     def backward(ctx, g):
         mod, w = ctx.mod, ctx.w
+        _check_stamp(ctx, w)
         mod._ensure_grads()
         w.dpred.copy_(g.reshape(w.Mm, -1))
         mod._rt.begin_backward()
@@ -162,6 +179,7 @@ class _ModelFn(torch.autograd.Function):
         rt.store.refresh_shadow()
         rt.forward(w)
         ctx.mod, ctx.w, ctx.fused = mod, w, fused
+        _stamp(ctx, w)
         if fused:
             rt.loss_forward(w, normalize, grad_scale)
             return w.loss.clone().reshape(())
@@ -170,6 +188,7 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         mod, w = ctx.mod, ctx.w
+        _check_stamp(ctx, w)
         mod._ensure_grads()
         if ctx.fused:
             # d(loss)/d(pred) was produced by the loss kernel for an upstream gradient of exactly 1 (what

@@ -293,6 +293,22 @@ def test_standalone_encoder_decoder(dev):
     assert _rel(xg.grad, xr.grad) < 3e-2
 
 
+def test_backward_through_overwritten_forward_is_refused(dev):
+    """one set of saved activations per batch size: backward through an output whose activations a later forward replaced
+    must raise instead of returning wrong gradients; the latest forward still back-propagates"""
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    model, _ = _build(cfg, "xavier", dev)
+    x = O.keyed_clips(2, cfg).to(dev)
+    mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool().to(dev)
+    first = model.forward_loss(x, mask)
+    second = model.forward_loss(x * 0.5, mask)
+    with pytest.raises(RuntimeError, match="stale forward"):
+        first.backward()
+    second.backward()
+    assert float(model.runtime().grad_norm()) > 0
+
+
 def test_bad_mask_is_reported(dev):
     from oracle import pretrain_oracle as O
     model, _ = _build(O.TINY, "small", dev)
