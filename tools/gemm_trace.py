@@ -62,6 +62,9 @@ assert lib.mofo_debug_trace_read(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(-1, 8)
 t = t[t[:, 0] > 0]
 nb = len(t)
+if nb == 0:
+    sys.exit("no stamped tiles: the persistent / split-K forms stamp a block's THIRD tile and this grid gives every block fewer; "
+             "force the one-tile-per-block form with MOFO_GEMM_VARIANT=1 MOFO_GEMM_MI8=0")
 ts = t[:, :6].astype(np.int64)
 base = ts[:, 0].min()
 hw = t[:, 7]
