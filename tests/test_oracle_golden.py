@@ -227,3 +227,19 @@ def test_clipped_steps_match_reference_scaler():
     assert all(n > float(g["clip_grad"]) for n in g["norms"])          # the clip really bites
     for i, n in enumerate(str(s) for s in g["names"]):
         assert float(P[n].double().norm()) == pytest.approx(g["param_stats_after3"][i, 0], rel=1e-5, abs=1e-7), n
+
+
+def test_vit_large_32_frames_matches_reference_classes():
+    """BASELINE config 4's shapes (ViT-L widths, 32 frames -> 3136 tokens, 320 visible; 3 + 1 blocks): the oracle against the
+    reference classes with their two position tables rebuilt for 32 frames (tests/golden/vitl32.npz)"""
+    g = _load("vitl32.npz")
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=3, enc_heads=16, dec_dim=512, dec_depth=1, dec_heads=8)
+    P = O.keyed_params(cfg, "xavier")
+    x = O.keyed_clips(1, cfg)
+    mask = torch.from_numpy(g["mask"]).bool()
+    np.random.seed(7)
+    assert np.array_equal(O.tube_mask(cfg.grid, 0.9)[None].astype(np.uint8), g["mask"])
+    loss, gn, grads = O.train_step(x, mask, P, cfg)
+    assert loss == pytest.approx(float(g["loss"]), rel=1e-5) and gn == pytest.approx(float(g["grad_norm"]), rel=1e-4)
+    for i, n in enumerate(str(s) for s in g["names"]):
+        assert float(grads[n].double().norm()) == pytest.approx(g["grad_stats"][i, 0], rel=2e-3, abs=1e-7), n

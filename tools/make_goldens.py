@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-vitb", action="store_true")
     ap.add_argument("--only-next", action="store_true", help="only the fixtures of the SURVEY 8f 'next' rows (vis.npz, finetune_*.npz)")
+    ap.add_argument("--only-l32", action="store_true", help="only vitl32.npz: ViT-L widths at 32 frames (BASELINE config 4 shapes) through the reference classes")
     ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
@@ -141,6 +142,9 @@ def main():
         return
     if args.only_clip:
         make_clip(args, ref_mp, ref_of, ref_utils, O)
+        return
+    if args.only_l32:
+        make_l32(args, ref_mp, ref_mf, O)
         return
 
     # ------------------------------------------------------------------ F1 masks
@@ -373,6 +377,44 @@ def main():
                         names=np.array(names), grad_stats=gstat, grad_head=ghead,
                         out_slice=out0[:, :6, :48].numpy(), out_sum=np.array(out0.double().sum().item()))
     print("vitb_bb: loss", losses, "gn", norms)
+
+
+def make_l32(args, ref_mp, ref_mf, O):
+    """vitl32.npz: BASELINE config 4's shapes -- ViT-L widths (1024 x 16 heads / 512 x 8 heads), 32 x 224 x 224 clips ->
+    3136 tokens, 320 visible -- through the REFERENCE classes, 3 encoder + 1 decoder blocks (the full depth adds nothing
+    new per block and this keeps the fixture a few-second job).  The reference hard-wires 16 frames in its position tables
+    (modeling_pretrain.py:52-55,199-200: built for patch_embed.num_patches of a 16-frame clip); the two tables are rebuilt
+    with the reference's own get_sinusoid_encoding_table for 3136 positions -- the documented deviation of SURVEY.md 5 / 8c F6."""
+    import contextlib
+    import io
+    from functools import partial as _partial
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=3, enc_heads=16, dec_dim=512, dec_depth=1, dec_heads=8)
+    P = O.keyed_params(cfg, "xavier")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref_mp.PretrainVisionTransformer(
+            img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+            encoder_num_heads=cfg.enc_heads, encoder_num_classes=0, decoder_num_classes=cfg.patch_dim, decoder_embed_dim=cfg.dec_dim,
+            decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+            norm_layer=_partial(torch.nn.LayerNorm, eps=1e-6))
+    model.load_state_dict(P, strict=True)
+    model.encoder.pos_embed = ref_mf.get_sinusoid_encoding_table(cfg.num_patches, cfg.enc_dim)
+    model.pos_embed = ref_mf.get_sinusoid_encoding_table(cfg.num_patches, cfg.dec_dim)
+    videos = O.keyed_clips(1, cfg)
+    np.random.seed(7)
+    import masking_generator as ref_mg
+    mask = torch.from_numpy(ref_mg.TubeMaskingGenerator(cfg.grid, 0.9)()[None]).bool()
+    assert mask.shape[1] == 3136 and int((~mask).sum()) == 320
+    labels = O.build_targets(videos, mask, cfg)          # the target builder is pinned by engine_vitb.npz (reference engine capture)
+    out = model(videos, mask)
+    loss = torch.nn.MSELoss()(out, labels)
+    loss.backward()
+    grads = {k: p.grad.detach() for k, p in model.named_parameters()}
+    names, gstat, ghead = tensor_stats(grads)
+    gn = float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values())))
+    np.savez_compressed(os.path.join(args.out, "vitl32.npz"), mask=mask.numpy().astype(np.uint8), loss=np.array(loss.item()), grad_norm=np.array(gn),
+                        names=np.array(names), grad_stats=gstat, grad_head=ghead, out_slice=out[:, :6, :48].detach().numpy(),
+                        out_sum=np.array(out.detach().double().sum().item()))
+    print("vitl32: loss", loss.item(), "grad norm", gn, "out_sum", out.detach().double().sum().item())
 
 
 def make_clip(args, ref_mp, ref_of, ref_utils, O):
