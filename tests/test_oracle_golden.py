@@ -172,6 +172,21 @@ def test_vitb_bb_masks_parity():
     assert float(loss) == pytest.approx(float(g["loss"]), rel=1e-5)
 
 
+def test_vitb_bb_engine_step_matches_reference_loop():
+    """one step of the reference's OWN motion-box epoch loop (train_one_epoch_BB, tests/golden/engine_vitb_bb.npz): the
+    oracle's loss, gradient norm and per-tensor gradient norms"""
+    g = _load("engine_vitb_bb.npz")
+    m = _load("masks.npz")
+    cfg = O.VIT_B
+    P = O.keyed_params(cfg, "xavier")
+    x = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(m["bb_s10"][g["pick"]]).bool()
+    loss, gn, grads = O.train_step(x, mask, P, cfg)
+    assert loss == pytest.approx(float(g["loss"]), rel=1e-5) and gn == pytest.approx(float(g["grad_norm"]), rel=1e-4)
+    for i, n in enumerate(str(s) for s in g["names"]):
+        assert float(grads[n].double().norm()) == pytest.approx(g["grad_stats"][i, 0], rel=2e-3, abs=1e-7), n
+
+
 # ----------------------------------------------------------------------------- "next" rows (SURVEY.md 8f-4)
 def _vis_inputs():
     g = _load("vis.npz")

@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--skip-vitb", action="store_true")
     ap.add_argument("--only-next", action="store_true", help="only the fixtures of the SURVEY 8f 'next' rows (vis.npz, finetune_*.npz)")
+    ap.add_argument("--only-bb-engine", action="store_true", help="only engine_vitb_bb.npz: one step of the reference's own train_one_epoch_BB")
     ap.add_argument("--only-l32", action="store_true", help="only vitl32.npz: ViT-L widths at 32 frames (BASELINE config 4 shapes) through the reference classes")
     ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
     args = ap.parse_args()
@@ -145,6 +146,9 @@ def main():
         return
     if args.only_l32:
         make_l32(args, ref_mp, ref_mf, O)
+        return
+    if args.only_bb_engine:
+        make_bb_engine(args, ref_mp, ref_of, ref_utils, ref_eng, O)
         return
 
     # ------------------------------------------------------------------ F1 masks
@@ -377,6 +381,52 @@ def main():
                         names=np.array(names), grad_stats=gstat, grad_head=ghead,
                         out_slice=out0[:, :6, :48].numpy(), out_sum=np.array(out0.double().sum().item()))
     print("vitb_bb: loss", losses, "gn", norms)
+
+
+def make_bb_engine(args, ref_mp, ref_of, ref_utils, ref_eng, O):
+    """engine_vitb_bb.npz: ONE step of the reference's own motion-box epoch loop (engine_for_pretraining.py:215-468,
+    train_one_epoch_BB) on ViT-B, B=2, batch = (videos, boxes int [16,4], BB masks) -- loss, grad norm, lr, weight decay and
+    the per-tensor gradient norms.  Stand-ins: a scaler whose state_dict has 'scale' (the disabled GradScaler's is empty)
+    and a no-op torch.cuda.synchronize; this loop's PNG dump is commented out in the reference."""
+    import contextlib
+    import io
+
+    class OptArgs:
+        opt, lr, weight_decay, opt_eps, opt_betas, momentum = "adamw", 1.5e-4, 0.05, 1e-8, (0.9, 0.95), 0.9
+
+    class Scaler(ref_utils.NativeScalerWithGradNormCount):
+        def state_dict(self):
+            return {"scale": 1.0}
+
+    cfg = O.VIT_B
+    masks = np.load(os.path.join(args.out, "masks.npz"))
+    P = O.keyed_params(cfg, "xavier")
+    videos = O.keyed_clips(2, cfg)
+    pick = [0, 3]
+    bbm = torch.from_numpy(masks["bb_s10"][pick].astype(np.float64))                         # collate: f64 [B,1568]
+    boxes = torch.from_numpy(np.stack([np.tile(masks["bb_boxes"][i], (16, 1)) for i in pick]))   # int64 [B,16,4]
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref_mp.pretrain_videomae_base_patch16_224(decoder_depth=4)
+    model.load_state_dict(P, strict=True)
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = ref_of.create_optimizer(OptArgs, model)
+        lr_sched = ref_utils.cosine_scheduler(1.5e-4, 1e-5, 2, 1, warmup_epochs=0)
+        wd_sched = ref_utils.cosine_scheduler(0.05, 0.05, 2, 1)
+    real_sync = torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            stats = ref_eng.train_one_epoch_BB(model, [(videos, boxes, bbm)], opt, torch.device("cpu"), 0, Scaler(), max_norm=None,
+                                               patch_size=16, normlize_target=True, start_steps=0, lr_schedule_values=lr_sched,
+                                               wd_schedule_values=wd_sched)
+    finally:
+        torch.cuda.synchronize = real_sync
+    grads = {k: p.grad.detach() for k, p in model.named_parameters()}
+    names, gstat, ghead = tensor_stats(grads)
+    np.savez_compressed(os.path.join(args.out, "engine_vitb_bb.npz"), pick=np.array(pick), loss=np.array(stats["loss"]),
+                        grad_norm=np.array(float(stats["grad_norm"])), lr=np.array(stats["lr"]), weight_decay=np.array(stats["weight_decay"]),
+                        names=np.array(names), grad_stats=gstat)
+    print("engine_vitb_bb:", {k: float(v) for k, v in stats.items()})
 
 
 def make_l32(args, ref_mp, ref_mf, O):
