@@ -98,6 +98,9 @@ def main():
     backend = os.environ.get("MOFO_DIST_BACKEND", "nccl")
     if backend != "nccl":
         local %= max(1, torch.cuda.device_count())
+    elif torch.cuda.device_count() <= local or (world > 1 and torch.cuda.device_count() < int(os.environ.get("LOCAL_WORLD_SIZE", world))):
+        raise SystemExit(f"bench.py --gpus {args.gpus}: rank {rank} (local {local}) needs its own GPU over RCCL but this node shows "
+                         f"{torch.cuda.device_count()} device(s); launch one rank per GPU (MOFO_DIST_BACKEND=gloo rehearses on one GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     import torch.distributed as dist
@@ -107,6 +110,14 @@ def main():
             dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
         else:
             dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+        # the communicator really spans `world` ranks: a SUM all-reduce of ones (run_mae_pretraining.py:225-227's group)
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        dist.all_reduce(ones)
+        rccl_ranks = int(round(float(ones.item())))
+        if rccl_ranks != dist.get_world_size() or rccl_ranks != world:
+            raise SystemExit(f"collective backend '{backend}' sees {rccl_ranks} ranks, expected {world}")
+    else:
+        rccl_ranks = 1
 
     from mofo_amd import _lib, optim_factory, utils
     from mofo_amd import modeling_pretrain as mp
@@ -185,10 +196,14 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    if world > 1 or force_dp:
+        opt.measure_exposed = True           # event pairs around each wait for a gradient range's all-reduce (FusedAdamW.step)
     t0 = time.perf_counter()
     last = None
+    step_ends = []
     for it in range(args.steps):
-        last = step(args.warmup + it)
+        last = step(args.warmup + it)        # ends with the reference's device synchronize: the host clock sees whole steps
+        step_ends.append(time.perf_counter())
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,6 +214,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     clips_per_s = B * world * args.steps / dt
+    per_step_ms = np.diff(np.array([t0] + step_ends)) * 1e3
+    exposed_ms = None
+    if getattr(opt, "measure_exposed", False) and opt.exposed_events:
+        # time the compute stream spent waiting for gradient exchanges that had not finished when the optimizer reached them
+        ex = [sum(a.elapsed_time(b) for a, b in ev) for ev in opt.exposed_events]
+        exposed_ms = float(np.median(ex))
+        if world > 1:
+            t = torch.tensor([exposed_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exposed_ms = float(t.item())
 
     out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step" if args.model == "vitb16" else "clips/sec (32x3x224x224, mask 90%) ViT-L pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -206,7 +231,9 @@ def main():
            "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
                                   "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),
-                      "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4)}}
+                      "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4),
+                      "ms_per_step_median": round(float(np.median(per_step_ms)), 3), "rccl_ranks": rccl_ranks, "backend": backend if (world > 1 or force_dp) else None,
+                      "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 3)}}
 
     if prof is not None:
         summ = prof.summary()
@@ -226,20 +253,26 @@ def main():
                            "unit": "TFLOP/s" if is_mfma else "GB/s", "frac": round(ach / (PEAK_BF16 if is_mfma else PEAK_HBM), 4),
                            "traffic": None, "launches": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
                            "share_of_kernel_time": round(d["ms"] / total_ms, 3)}
-        # HBM-side traffic of the dominant kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
-        # (tools/pmc_step.sh; FETCH_SIZE doubled as the guide prescribes for gfx950), committed under profiles/ -- counters
-        # cannot be read from inside the process, so this is the recorded figure, null if the file is absent
-        kern = {"gemm_tn_wgrad_f32": "gemm_kernel<1, 1, 5, 1, 4>"}.get(out["roofline"]["kernel"])
-        tpath = os.path.join(ROOT, "profiles", "r01_pmc_step_traffic.json")
-        if kern and args.model == "vitb16" and B == 32 and os.path.exists(tpath):   # recorded for the headline workload only
+        out["roofline"]["dropped_launches"] = d["dropped"]
+        # algorithmic bytes of one launch, from the launches' own shapes (every operand read once, every output written
+        # once; ops._gemm_args) -- not a constant
+        if d.get("bytes"):
+            out["roofline"]["algorithmic_bytes"] = round(d["bytes"] / d["launches"])
+        # HBM-side traffic of the dominant class: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over THIS command
+        # (tools/pmc_step.sh; FETCH_SIZE doubled as the guide prescribes for gfx950).  Counters cannot be read from inside the
+        # process, so this is a RECORDED figure: it is reported only while the kernel sources are byte-identical to the ones
+        # the profile was taken with (sha256 over mofo_amd/csrc), null otherwise.
+        tpath = os.path.join(ROOT, "profiles", "r02_pmc_step_traffic.json")
+        out["roofline"]["traffic_source"] = None
+        if args.model == "vitb16" and B == 32 and os.path.exists(tpath):   # recorded for the headline workload only
             try:
-                rec = json.load(open(tpath)).get(kern)
-                if rec:
+                prof_rec = json.load(open(tpath))
+                rec = prof_rec.get("classes", {}).get(out["roofline"]["kernel"])
+                if prof_rec.get("_meta", {}).get("csrc_sha256") != csrc_sha():
+                    out["roofline"]["traffic_source"] = "stale: profiles/r02_pmc_step_traffic.json was recorded for other kernel sources"
+                elif rec:
                     out["roofline"]["traffic"] = round((rec["fetch_MB_per_launch"] + rec["write_MB_per_launch"]) * 1e6)
-                    out["roofline"]["traffic_unit"] = "bytes per launch (rocprofv3 PMC passes of this command, profiles/r01_pmc_step_traffic.json)"
-                    if kern.startswith("gemm_kernel<1, 1, 5"):
-                        # operands read once + f32 weight gradients written once, averaged over the step's 19 launches
-                        out["roofline"]["algorithmic_bytes"] = round((4186.0e6 + 377.0e6) / 19)
+                    out["roofline"]["traffic_source"] = "recorded: profiles/r02_pmc_step_traffic.json (csrc sha256 %s)" % csrc_sha()[:12]
             except Exception:
                 pass
         gem = [warm[k] for k in warm if k[0] == "gemm"]
@@ -296,6 +329,17 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()
+
+
+def csrc_sha() -> str:
+    """sha256 over the kernel sources (mofo_amd/csrc, sorted by name): ties a recorded PMC profile to the code it measured"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "mofo_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()
 
 
 def host_cores() -> int:

@@ -95,15 +95,19 @@ class EventProfiler:
             return
         e0 = torch.cuda.Event(enable_timing=True)
         e0.record(stream) if stream is not None else e0.record()
-        self._cur = (key, work, e0)
+        # ``work`` is FLOPs (MFMA classes) or bytes (HBM classes); the GEMM wrappers pass (FLOPs, algorithmic bytes)
+        nbytes = 0.0
+        if isinstance(work, tuple):
+            work, nbytes = work
+        self._cur = (key, work, e0, nbytes)
 
     def end(self, stream=None):
         if self._cur is None:
             return
-        key, work, e0 = self._cur
+        key, work, e0, nbytes = self._cur
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record(stream) if stream is not None else e1.record()
-        self.records.append((key, work, e0, e1))
+        self.records.append((key, work, e0, e1, nbytes))
 
     def summary(self):
         """per class: launches, total ms, total work, max ms.  A launch that took more than 10x its class's 90th percentile
@@ -111,15 +115,15 @@ class EventProfiler:
         is left out and counted in 'dropped'."""
         torch.cuda.synchronize()
         per = {}
-        for key, work, e0, e1 in self.records:
-            per.setdefault(key, []).append((e0.elapsed_time(e1), work))
+        for key, work, e0, e1, nbytes in self.records:
+            per.setdefault(key, []).append((e0.elapsed_time(e1), work, nbytes))
         out = {}
         for key, lst in per.items():
-            ts = sorted(t for t, _ in lst)
+            ts = sorted(t for t, _, _ in lst)
             p90 = ts[min(len(ts) - 1, (9 * len(ts)) // 10)]
-            keep = [(t, w) for t, w in lst if t <= 10.0 * p90 or len(lst) < 20]
-            out[key] = {"launches": len(keep), "ms": sum(t for t, _ in keep), "work": sum(w for _, w in keep),
-                        "max_ms": max(t for t, _ in keep), "dropped": len(lst) - len(keep)}
+            keep = [(t, w, b) for t, w, b in lst if t <= 10.0 * p90 or len(lst) < 20]
+            out[key] = {"launches": len(keep), "ms": sum(t for t, _, _ in keep), "work": sum(w for _, w, _ in keep),
+                        "bytes": sum(b for _, _, b in keep), "max_ms": max(t for t, _, _ in keep), "dropped": len(lst) - len(keep)}
         return out
 
 

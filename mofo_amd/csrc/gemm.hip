@@ -111,12 +111,14 @@ __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int 
     for (int j = 0; j < NI; ++j) {
         const int i = wave_u * NI + j;
         if constexpr (LAYOUT == OPL_ROW) {
-            const int soff = ((d0 + 8 * i) * ld + k0) * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, soff, 0, 0);
+            // unsigned: a tile row offset past the operand (ragged last tile) may exceed INT_MAX bytes for operands close to
+            // the 2 GiB extent limit that fill_problem enforces; the SRD range check then reads zeros
+            const unsigned soff = ((unsigned)(d0 + 8 * i) * (unsigned)ld + (unsigned)k0) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, 0);
         } else {
             static_assert(LAYOUT == OPL_ROW || NI == 4, "piece parity below assumes 4 pieces per wave");
-            const int soff = ((k0 + 4 * i) * ld + d0) * 2;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, soff, 0, 0);
+            const unsigned soff = ((unsigned)(k0 + 4 * i) * (unsigned)ld + (unsigned)d0) * 2u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, (int)soff, 0, 0);
         }
     }
 }
@@ -776,6 +778,19 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
     if (epi == MOFO_EPI_RESID_F32 && (!a->resid || a->ldr % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_F32 needs resid (ldr multiple of 4)");
     if (epi == MOFO_EPI_DGELU_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: DGELU needs aux (ldaux multiple of 8)");
     if (epi == MOFO_EPI_POS_F32 && (!a->pos || !a->row_idx || a->rows_in <= 0 || a->ldpos % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
+    {
+        // the operands are addressed through 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets):
+        // an operand image of 2 GiB or more is refused instead of wrapping (split the rows / the reduction on the caller's side)
+        const long long ra = op == MOFO_GEMM_TN ? a->K : a->M, ca = op == MOFO_GEMM_TN ? a->M : a->K;
+        const long long rb = op == MOFO_GEMM_NT ? a->N : a->K, cb = op == MOFO_GEMM_NT ? a->K : a->N;
+        const long long ext_a = ((ra - 1) * a->lda + ca) * 2, ext_b = ((rb - 1) * a->ldb + cb) * 2;
+        // + one ragged tile of slack: offsets of rows past the end are formed before the range check drops them
+        const long long slack = 256LL * (a->lda > a->ldb ? a->lda : a->ldb) * 2;
+        if (ext_a + slack >= (1LL << 31) || ext_b + slack >= (1LL << 31))
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: operand extent %lld / %lld bytes is beyond the 2 GiB the 32-bit buffer offsets address",
+                      ext_a, ext_b);
+        if (a->lda < ca || a->ldb < cb) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: leading dimension smaller than the row length");
+    }
     p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.C = a->C; p.C2 = a->C2;
     p.bias = a->bias; p.resid = a->resid; p.aux = (const bf16_t*)a->aux; p.pos = a->pos; p.row_idx = a->row_idx;
     p.M = a->M; p.N = a->N; p.K = a->K;

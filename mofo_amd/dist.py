@@ -22,6 +22,7 @@ class GradSync:
         import os
         ws = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 0
         self.enabled = ws > 1 or (ws == 1 and os.environ.get("MOFO_FORCE_DP") == "1")
+        self.world_size = max(ws, 1)
         self.launched: List[tuple] = []
 
     def install(self):
@@ -77,6 +78,9 @@ class DataParallel(torch.nn.Module):
         self.world_size = dist.get_world_size(process_group) if self.sync.enabled else 1
 
     def forward(self, *a, **k):
+        """the reference call ``model(videos, mask)`` followed by a torch loss: the 1/world scale of the SUM exchange is
+        applied to the upstream gradient inside the model's backward (modeling_pretrain._ModelFn), as forward_loss() does
+        through the loss kernel -- both paths leave DDP's mean gradient on every rank"""
         return self.module(*a, **k)
 
     def forward_loss(self, x, mask, normlize_target=True, grad_scale=None):

@@ -196,7 +196,12 @@ class _ModelFn(torch.autograd.Function):
             # Kept by reference and compared at the status check: doing it here cost four tiny torch launches per step.
             w.upstream = g
         else:
-            w.dpred.copy_(g.reshape(w.Mm, -1))
+            # generic path (model(x, mask) + a torch loss): under data parallelism the exchange is a SUM all-reduce, so the
+            # upstream gradient is scaled by 1/world here -- what forward_loss() folds into the loss kernel's grad_scale --
+            # and every rank ends up with DDP's MEAN gradient (run_mae_pretraining.py:225-227) on both paths
+            gs = getattr(mod, "_grad_sync", None)
+            sc = 1.0 / gs.world_size if (gs is not None and gs.enabled and gs.world_size > 1) else 1.0
+            w.dpred.copy_(g.reshape(w.Mm, -1) if sc == 1.0 else g.reshape(w.Mm, -1) * sc)
         mod._rt.backward(w)
         return None, None, None, None, None, None
 

@@ -111,8 +111,8 @@ def replay(launches):
 
 def gemm(op, epi, A, B, C_, **kw):
     """C = epilogue(A (op) B).  A, B bf16 2-D; see include/mofo_hip.h for op / epilogue semantics."""
-    a, flops = _gemm_args(op, epi, A, B, C_, **kw)
-    _run("mofo_gemm", ("gemm", op, epi), flops, C.byref(a))
+    a, flops, nbytes = _gemm_args(op, epi, A, B, C_, **kw)
+    _run("mofo_gemm", ("gemm", op, epi), (flops, nbytes), C.byref(a))
     return C_
 
 
@@ -120,7 +120,7 @@ def gemm_grouped(op, epi, problems):
     """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 4)"""
     built = [_gemm_args(op, epi, A, B, C_, **kw) for A, B, C_, kw in problems]
     arr = (GemmArgs * len(built))(*[b[0] for b in built])
-    _run("mofo_gemm_grouped", ("gemm", op, epi), sum(b[1] for b in built), arr, len(built))
+    _run("mofo_gemm_grouped", ("gemm", op, epi), (sum(b[1] for b in built), sum(b[2] for b in built)), arr, len(built))
 
 
 def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
@@ -175,7 +175,18 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
                  rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0, colsum=_p(colsum),
                  colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1])
-    return a, 2.0 * M * N * K
+    # algorithmic HBM bytes of the launch: every operand read once, every output written once (bench.py's roofline block)
+    esz = 4.0 if out_dtype == F32 else 2.0
+    nbytes = 2.0 * (M * K + N * K) + esz * M * N
+    if epi == EPI_BIAS_GELU:
+        nbytes += 2.0 * M * N
+    elif epi == EPI_RESID_F32:
+        nbytes += resid.element_size() * M * N
+    elif epi == EPI_DGELU_BF16:
+        nbytes += 2.0 * M * N
+    elif epi == EPI_POS_F32:
+        nbytes += 4.0 * M * N
+    return a, 2.0 * M * N * K, nbytes
 
 
 def colsum_bf16(X, out):

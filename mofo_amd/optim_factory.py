@@ -42,6 +42,8 @@ class FusedAdamW(torch.optim.Optimizer):
         self._step = 0
         self.exp_avg = None
         self.exp_avg_sq = None
+        self.measure_exposed = False      # bench.py: event pairs around the waits for the data-parallel gradient ranges
+        self.exposed_events = []          # one list of (start, end) events per step while measure_exposed is on
         self._bind()
 
     def _bind(self):
@@ -53,23 +55,41 @@ class FusedAdamW(torch.optim.Optimizer):
             self._store = st
             self.exp_avg = torch.zeros_like(st.params)
             self.exp_avg_sq = torch.zeros_like(st.params)
+            self._verify_groups(st)
         return rt, st
+
+    def _verify_groups(self, st):
+        """The kernel picks decay / no-decay per 1024-element chunk from the flat store's table (built from the model's
+        no_weight_decay() and the reference's rule, optim_factory.py:56-61) and reads ONE betas / eps: param_groups that
+        say something else (a custom skip_list, filter_bias_and_bn=False with a non-zero decay on biases, per-group betas)
+        would be reported but not applied -- refuse them instead."""
+        if len(self.param_groups) > 2:
+            raise NotImplementedError("the fused AdamW applies two groups (decay / no decay), got %d" % len(self.param_groups))
+        g0 = self.param_groups[0]
+        for g in self.param_groups[1:]:
+            if tuple(g["betas"]) != tuple(g0["betas"]) or g["eps"] != g0["eps"]:
+                raise NotImplementedError("the fused AdamW applies one betas / eps to every group")
+        if not all("_decayed" in g for g in self.param_groups):
+            return      # groups restored from a foreign checkpoint are tagged in load_state_dict
+        names = {id(p): n for n, p in self.model.named_parameters()}
+        table = st.chunk_group.cpu().numpy()
+        for g in self.param_groups:
+            want = 0 if g["_decayed"] else 1
+            for p in g["params"]:
+                n = names.get(id(p))
+                if n is None:
+                    raise ValueError("optimizer parameter is not a parameter of the bound model")
+                o = st.offset[n]
+                if int(table[o // 1024]) != want:
+                    raise NotImplementedError(f"{n}: param_groups put it in the {'decay' if g['_decayed'] else 'no-decay'} group but the "
+                                              "flat store's chunk table (model.no_weight_decay() + the reference's 1-D / .bias rule) says "
+                                              "otherwise; the fused kernel would apply the table")
 
     def zero_grad(self, set_to_none: bool = False):
         _, st = self._bind()
         st.zero_grads()
         if not st.grads_attached():
             st.attach_grads()
-
-    def _group(self, decayed: bool):
-        for g in self.param_groups:
-            if (g["weight_decay"] > 0) == decayed or len(self.param_groups) == 1:
-                return g
-        # both groups may carry weight_decay 0 (wd schedule at 0): fall back to creation tags
-        for g in self.param_groups:
-            if g.get("_decayed", None) == decayed:
-                return g
-        return self.param_groups[0]
 
     @torch.no_grad()
     def step(self, closure=None, grad_norm=None, max_norm=0.0, norm_out=None, ranges=None):
@@ -101,15 +121,26 @@ class FusedAdamW(torch.optim.Optimizer):
             if getattr(self, "_range_partial", None) is None or self._range_partial.numel() < slots:
                 self._range_partial = torch.empty(max(slots, 1), dtype=torch.float32, device=st.params.device)
             covered, slot = 0, 0
+            measure = getattr(self, "measure_exposed", False)
+            pairs = []
             for lo, hi, wait in ranges:
                 if lo % 1024 or hi % 1024 or hi <= lo:
                     raise ValueError(f"range [{lo}, {hi}) is not a 1024-aligned slice of the flat buffers")
-                wait()
+                if measure:     # bench.py: how long the compute stream idles for this range's exchange (0 when it had landed)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    wait()
+                    e1.record()
+                    pairs.append((e0, e1))
+                else:
+                    wait()
                 nb = ops.adamw_blocks(hi - lo)
                 ops.adamw(st.params[lo:hi], st.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], st.shadow[lo:hi],
                           st.chunk_group[lo // 1024:hi // 1024], *hyper, norm_partial=self._range_partial[slot:slot + nb] if norm_out is not None else None)
                 slot += nb
                 covered += hi - lo
+            if measure:
+                self.exposed_events.append(pairs)
             if covered != st.params.numel():
                 raise RuntimeError(f"ranges cover {covered} of {st.params.numel()} elements")
             if norm_out is not None:

@@ -1,5 +1,6 @@
-"""Worker of test_two_ranks_share_one_gpu_like_the_8_gpu_job (launched by torch.distributed.run, one process per rank).
-Both ranks use cuda:0 and exchange through gloo (RCCL refuses two ranks on one device); everything else -- DataParallel's
+"""Worker of test_ranks_share_one_gpu_like_the_multi_gpu_job (launched by torch.distributed.run, one process per rank).
+By default all ranks use cuda:0 and exchange through gloo (RCCL refuses two ranks on one device; MOFO_DP_TEST_BACKEND=nccl
+puts one rank on each GPU over RCCL where the box has them); everything else -- DataParallel's
 flat broadcast, the per-bucket asynchronous all-reduce issued from inside the replayed backward, the join before the fused
 AdamW -- is the code the multi-GPU job runs.  Each rank trains on its shard of a fixed global batch and reports its loss and
 parameters; rank 0 writes the comparison next to the single-process run over the whole batch."""
@@ -32,7 +33,7 @@ def build(cfg, dev):
     return model.to(dev)
 
 
-def train(model, wrapped, x, mask, steps):
+def train(model, wrapped, x, mask, steps, labels):
     opt = optim_factory.create_optimizer(Args, model)
     scaler = utils.NativeScalerWithGradNormCount()
     losses = []
@@ -54,15 +55,30 @@ def train(model, wrapped, x, mask, steps):
         losses.append(float(loss.detach()))
     model.check_status()
     torch.cuda.synchronize()
-    return losses, model.runtime().store.params.detach().clone(), grads, norms
+    params = model.runtime().store.params.detach().clone()
+    # the reference call pattern -- model(videos, mask) + nn.MSELoss on the outputs (engine_for_pretraining.py:66-67) --
+    # must leave the same MEAN gradient under data parallelism as the fused path (the 1/world scale sits in the backward)
+    out = wrapped(x, mask)
+    opt.zero_grad()
+    torch.nn.MSELoss()(out, labels.to(out.device)).backward()
+    if sync is not None:
+        sync.finish()
+    generic = model.runtime().store.grads.detach().clone()
+    torch.cuda.synchronize()
+    return losses, params, grads, norms, generic
 
 
 def main():
     out_path = sys.argv[1]
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    dev = torch.device("cuda:0")
+    # MOFO_DP_TEST_BACKEND=nccl: one GPU per rank over RCCL (a box with >= world GPUs); default: every rank on cuda:0 over gloo
+    backend = os.environ.get("MOFO_DP_TEST_BACKEND", "gloo")
+    dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) if backend == "nccl" else 0)
     torch.cuda.set_device(dev)
-    dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
+    if backend == "nccl":
+        dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+    else:
+        dist.init_process_group("gloo", init_method="env://", world_size=world, rank=rank)
     cfg = O.OracleConfig(img_size=64, enc_dim=192, enc_depth=6, enc_heads=3, dec_dim=128, dec_depth=2, dec_heads=2)
     per_rank, steps = 2, 3
     x_all = O.keyed_clips(per_rank * world, cfg)
@@ -77,21 +93,28 @@ def main():
     wrapped = DataParallel(model)
     assert wrapped.sync.enabled and wrapped.world_size == world
     n_seg = len(model.runtime().segments)
-    losses, params, grads, norms = train(model, wrapped, x_all[sl].to(dev), mask_all[sl].to(dev), steps)
+    labels_all = O.build_targets(x_all, mask_all, cfg)
+    losses, params, grads, norms, generic = train(model, wrapped, x_all[sl].to(dev), mask_all[sl].to(dev), steps, labels_all[sl])
     assert not wrapped.sync.handles
     params = params.cpu()
-    gathered = [torch.empty_like(params) for _ in range(world)] if rank == 0 else None
-    dist.gather(params, gathered, dst=0)
+    if backend == "nccl":
+        gathered = [torch.empty_like(params, device=dev) for _ in range(world)]
+        dist.all_gather(gathered, params.to(dev))
+        gathered = [g.cpu() for g in gathered]
+    else:
+        gathered = [torch.empty_like(params) for _ in range(world)] if rank == 0 else None
+        dist.gather(params, gathered, dst=0)
     all_losses = [None] * world
     dist.all_gather_object(all_losses, losses)
     if rank == 0:
         torch.manual_seed(100)                 # the single-process run over the WHOLE batch, from rank 0's initial weights
         ref_model = build(cfg, dev)
-        ref_losses, ref_params, ref_grads, ref_norms = train(ref_model, ref_model, x_all.to(dev), mask_all.to(dev), steps)
+        ref_losses, ref_params, ref_grads, ref_norms, ref_generic = train(ref_model, ref_model, x_all.to(dev), mask_all.to(dev), steps, labels_all)
         rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
         json.dump({"world": world, "segments": n_seg, "losses": all_losses, "ref_losses": ref_losses,
                    "rank_param_diff": [rel(g, gathered[0]) for g in gathered], "params_vs_single_process": rel(gathered[0], ref_params),
-                   "grads_vs_single_process": rel(grads, ref_grads), "norms": norms, "ref_norms": ref_norms}, open(out_path, "w"))
+                   "grads_vs_single_process": rel(grads, ref_grads), "norms": norms, "ref_norms": ref_norms,
+                   "generic_grads_vs_single_process": rel(generic, ref_generic), "backend": backend}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -178,6 +178,20 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.float(), B, C)
     with pytest.raises(ValueError):
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.cpu(), B, C)
+    # operands are addressed with 32-bit buffer offsets: an operand image of 2 GiB or more is refused, not wrapped
+    big = torch.empty((1 << 20) + 128, 1024, dtype=BF16, device=dev)          # 2 GiB + 256 KiB
+    Wt = _rand((128, 1024), dev, 3)
+    out = torch.empty(big.shape[0], 128, dtype=BF16, device=dev)
+    with pytest.raises(RuntimeError, match="2 GiB"):
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, big, Wt, out)
+    with pytest.raises(RuntimeError, match="2 GiB"):                          # ... as the reduction-strided operand of a wgrad
+        ops.gemm(ops.GEMM_TN, ops.EPI_F32, big, big[:, :128], torch.empty(1024, 128, dtype=torch.float32, device=dev))
+    # just below the limit still runs (1.75 GiB operand, ragged last tile) and agrees with torch on the last rows
+    ok = big[: 917504 - 40]
+    ok[-256:] = _rand((256, 1024), dev, 4)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, ok, Wt, out[: ok.shape[0]])
+    ref = ok[-256:].float() @ Wt.float().t()
+    assert float((out[ok.shape[0] - 256: ok.shape[0]].float() - ref).norm() / ref.norm()) < 1e-2
 
 
 def test_colsum(dev):
