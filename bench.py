@@ -242,7 +242,7 @@ def main():
         names = {("gemm", 0, 0): "gemm_nt_bf16", ("gemm", 0, 1): "gemm_nt_bias_gelu", ("gemm", 0, 2): "gemm_nt_resid_f32",
                  ("gemm", 0, 3): "gemm_nt_pos_f32", ("gemm", 1, 0): "gemm_nn_bf16", ("gemm", 1, 4): "gemm_nn_dgelu",
                  ("gemm", 2, 5): "gemm_tn_wgrad_f32"}
-        mfma_keys = [k for k in summ if k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv")]
+        mfma_keys = [k for k in summ if k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_1p")]
         total_ms = sum(v["ms"] for v in warm.values()) / max(1, n_instr) * args.steps
         dom = max(summ, key=lambda k: summ[k]["ms"])
         d = summ[dom]
@@ -284,7 +284,7 @@ def main():
             print("(per-class table from the fully instrumented warm-up steps)", file=sys.stderr)
             for k, v in sorted(warm.items(), key=lambda kv: -kv[1]["ms"]):
                 rate = v["work"] / (v["ms"] * 1e-3)
-                mf = k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv")
+                mf = k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_1p")
                 print(f"{names.get(k, '_'.join(str(x) for x in k)):28s} {v['launches'] // max(1, n_instr):8d} {v['ms'] / max(1, n_instr):9.3f} "
                       f"{v['ms'] / wtot:6.1%} {rate / (1e12 if mf else 1e9):9.1f} {'TF/s' if mf else 'GB/s'}  (max {v['max_ms']:.3f} ms)", file=sys.stderr)
             print(f"sum of kernel time {wtot / max(1, n_instr):.3f} ms/step (warm-up) vs timed wall {1e3 * dt / args.steps:.3f} ms/step", file=sys.stderr)

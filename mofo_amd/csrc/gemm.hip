@@ -46,6 +46,7 @@ struct GemmP {
     float* colsum;            // TN only: colsum[m] += sum_k A[k,m]  (bias gradient riding on the wgrad GEMM), or null
     int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
     int rotate;               // persistent form: rotated reduction order per tile (see gemm_persistent_kernel)
+    int nt_a;                 // A operand staged with non-temporal loads (persistent form)
     int rotate_tile;          // the same in the one-tile-per-block kernel (MOFO_GEMM_ROTATE_TILE=0 turns it off): small-grid
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
 };
@@ -104,7 +105,9 @@ __device__ __forceinline__ void srd_lane_offsets(int ld, int lane, int& v0, int&
         v1 = (kq * ld + g1 * 8) * 2;
     }
 }
-template <int LAYOUT, int NI>
+// AUX = 2: non-temporal load (an operand this launch streams ONCE, e.g. the activation rows of a tall forward GEMM) so that
+// it does not displace the weight panel every block of the XCD re-reads from its 4 MiB L2.
+template <int LAYOUT, int NI, int AUX = 0>
 __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int v0, int v1, int ld, int d0, int k0,
                                                unsigned char* lds_tile, int wave_u) {
 #pragma unroll
@@ -114,11 +117,11 @@ __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int 
             // unsigned: a tile row offset past the operand (ragged last tile) may exceed INT_MAX bytes for operands close to
             // the 2 GiB extent limit that fill_problem enforces; the SRD range check then reads zeros
             const unsigned soff = ((unsigned)(d0 + 8 * i) * (unsigned)ld + (unsigned)k0) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, AUX);
         } else {
             static_assert(LAYOUT == OPL_ROW || NI == 4, "piece parity below assumes 4 pieces per wave");
             const unsigned soff = ((unsigned)(k0 + 4 * i) * (unsigned)ld + (unsigned)d0) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, (int)soff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, (int)soff, 0, AUX);
         }
     }
 }
@@ -527,7 +530,8 @@ __global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(G
     auto stage = [&](int m0, int n0, int t) {
         int kc = t + m0 / BMT + n0 / BN;
         kc = p.rotate ? kc % nk : t;
-        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
+        if (p.nt_a) stage_tile_srd<LA, MI, 2>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
+        else stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
         stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, kc * BK, smem + A_BYTES, wave_u);
     };
     const unsigned char* ta = smem;
@@ -820,6 +824,12 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
             rt = e ? atoi(e) : 1;
         }
         p.rotate_tile = rt;
+        static int nta = -2;
+        if (nta == -2) {
+            const char* e = getenv("MOFO_GEMM_NT_A");
+            nta = e ? atoi(e) : 0;
+        }
+        p.nt_a = nta;
     }
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
     blocks = ceil_div(a->M, bm) * ceil_div(a->N, BN) * splits;
