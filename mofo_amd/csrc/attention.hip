@@ -27,9 +27,25 @@ __device__ unsigned long long g_attn_trace[1 << 18];
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.x < (1 << 15)) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
+// one-pass backward: waves 0 and 4 (the two waves of one SIMD) of every block, query block 2, step 3
+// (values are kept in registers and stored once at the end of the kernel: a global store per stamp would sit in vmcnt
+// and make the build's barriers wait for the LDS-DMA in flight, which the real build never does)
+#define OP_STAMP(qb, st, slot)                                                                     \
+    do {                                                                                           \
+        if ((qb) == 2 && (st) == 3) op_stamp[slot] = __builtin_readcyclecounter();                 \
+    } while (0)
+#define OP_STAMP_DECL unsigned long long op_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define OP_STAMP_FLUSH()                                                                           \
+    do {                                                                                           \
+        if ((threadIdx.x & 255) == 0 && blockIdx.x < (1 << 14))                                    \
+            for (int i_ = 0; i_ < 8; ++i_) g_attn_trace[blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + i_] = op_stamp[i_]; \
+    } while (0)
 #else
 #define ATTN_STAMP(kt, slot)
 #define FUSED_STAMP(slot)
+#define OP_STAMP(qb, st, slot)
+#define OP_STAMP_DECL
+#define OP_STAMP_FLUSH()
 #endif
 
 constexpr int HD = 64;
@@ -696,6 +712,82 @@ __global__ __launch_bounds__(OP_T * 64) void attn_bwd_onepass_kernel(const bf16_
 
     unsigned char* Sw = SC + wave * (32 * SCR);
     const unsigned char* Kw = KT + wave * TILE;
+    // ---- the three MFMA groups of a step.  Written as explicit load groups ahead of MFMA groups, pinned with sched_barrier:
+    // left to itself hipcc puts every fragment read directly in front of its MFMA (`ds_read; s_waitcnt lgkmcnt(0); v_mfma`
+    // x 20), and with two waves per SIMD nothing hides those LDS round trips.
+    bf16x8 pf0, pf1, sf0, sf1, t0, t1;                         // P, dS (packed B operands) and the scratch fragments of a step
+    bf16x8 ot00, ot10, ot01, ot11;                             // dO^T fragments (read under the score MFMAs, used by the dV MFMAs)
+    // S = Q K^T, dP = dO V^T (key on the lane), P = exp2(c S - lse2), dS = P (dP - delta); dS also goes to the scratch
+    auto pair_scores = [&](const unsigned char* Qt, const unsigned char* Ot, const float* Lt) {
+        const float* Dt = Lt + 32;
+        bf16x8 qa[4], ka[4], oa[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            qa[ks] = row_frag(Qt, ks, lane);
+            ka[ks] = row_frag(Kw, ks, lane);
+            oa[ks] = row_frag(Ot, ks, lane);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        f32x16 s = zero16(), dpv = zero16();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], ka[ks], s, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[ks], vf[ks], dpv, 0, 0, 0);
+        // dO^T fragments for dV: their LDS latency passes under the two MFMA chains and the exponentials
+        ot00 = tr_frag(Ot, 0, 0, lane), ot10 = tr_frag(Ot, 1, 0, lane), ot01 = tr_frag(Ot, 0, 1, lane), ot11 = tr_frag(Ot, 1, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        float p[16], ds[16];
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+            const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * rg + e;
+                const float pr = fast_exp2(s[r] * c - lv[e]);
+                p[r] = pr;
+                ds[r] = pr * (dpv[r] - dv[e]);
+            }
+        }
+        pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+        sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
+        // dS tile to the scratch as [key = lane & 31][query]; a key beyond N must not reach dQ
+        const int kr = lane & 31;
+        const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
+        const u32x2 z = {0u, 0u};
+        const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
+                            kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
+    };
+    // dV_j^T += dO^T P, dK_j^T += Q^T dS
+    auto pair_dvdk = [&](const unsigned char* Qt) {
+        const bf16x8 qt00 = tr_frag(Qt, 0, 0, lane), qt10 = tr_frag(Qt, 1, 0, lane), qt01 = tr_frag(Qt, 0, 1, lane), qt11 = tr_frag(Qt, 1, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot00, pf0, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot01, pf0, dv1, 0, 0, 0);
+        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot10, pf1, dv0, 0, 0, 0);
+        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot11, pf1, dv1, 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt00, sf0, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt01, sf0, dk1, 0, 0, 0);
+        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt10, sf1, dk0, 0, 0, 0);
+        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt11, sf1, dk1, 0, 0, 0);
+    };
+    // dQ_(slot wave)^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query]  (t0, t1: the scratch fragments of wave j)
+    auto slot_dq = [&](int j) {
+        const unsigned char* Kj = KT + j * TILE;
+        const bf16x8 k00 = tr_frag(Kj, 0, 0, lane), k10 = tr_frag(Kj, 1, 0, lane), k01 = tr_frag(Kj, 0, 1, lane), k11 = tr_frag(Kj, 1, 1, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00, t0, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k01, t0, q1, 0, 0, 0);
+        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k10, t1, q0, 0, 0, 0);
+        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k11, t1, q1, 0, 0, 0);
+    };
+    // (Measured and dropped: a partner stagger -- waves 4.. issuing a step's dV / dK and dQ MFMA groups at the start of the next
+    // step so that they run beside the SIMD partner's exponentials -- 590 vs 563 us: a wave's own chain operand reads -> 8 MFMAs
+    // -> ~130 VALU -> 8 MFMAs -> barrier -> 4 reads -> barrier -> 4 MFMAs is ~2 000 clk of latency per step by itself, and 256
+    // VGPRs allow no third wave per SIMD to fill it.)
     for (int qb = 0; qb < nqb; ++qb) {
         const int cur = qb & 1;
         const unsigned char* QT = QB + cur * OP_QBUF;
@@ -705,76 +797,21 @@ __global__ __launch_bounds__(OP_T * 64) void attn_bwd_onepass_kernel(const bf16_
         const int tq = min(OP_T, nkt - qb * OP_T);             // query tiles of this block
         const int tqn = qb + 1 < nqb ? min(OP_T, nkt - (qb + 1) * OP_T) : 0;
         for (int st = 0; st < OP_T; ++st) {
-            // The step is written as explicit load groups ahead of MFMA groups, pinned with sched_barrier: left to itself
-            // hipcc puts every fragment read directly in front of its MFMA (`ds_read; s_waitcnt lgkmcnt(0); v_mfma` x 20),
-            // and with fewer than two waves per SIMD nothing hides those LDS round trips (first version: 4 700 clk per step
-            // for 640 clk of MFMA).
+            const bool last = st == OP_T - 1;
             int jq = wave - st;
             jq = jq < 0 ? jq + OP_T : jq;                      // the wave whose key tile met query slot `wave` in this step
             const bool do_q = wave < tq && jq < tk;
             int qs = wave + st;
             qs = qs >= OP_T ? qs - OP_T : qs;                  // query slot this wave's key tile meets in this step
             if (has_key && qs < tq) {
-                const unsigned char* Qt = QT + qs * TILE;
-                const unsigned char* Ot = OT + qs * TILE;
-                const float* Lt = LD + qs * 64;
-                const float* Dt = Lt + 32;
-                bf16x8 qa[4], ka[4], oa[4];
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    qa[ks] = row_frag(Qt, ks, lane);
-                    ka[ks] = row_frag(Kw, ks, lane);
-                    oa[ks] = row_frag(Ot, ks, lane);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                f32x16 s = zero16(), dpv = zero16();
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], ka[ks], s, 0, 0, 0);
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[ks], vf[ks], dpv, 0, 0, 0);
-                // dO^T fragments for dV: their LDS latency passes under the two MFMA chains and the exponentials
-                const bf16x8 ot00 = tr_frag(Ot, 0, 0, lane), ot10 = tr_frag(Ot, 1, 0, lane), ot01 = tr_frag(Ot, 0, 1, lane), ot11 = tr_frag(Ot, 1, 1, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                float p[16], ds[16];
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
-                    const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * rg + e;
-                        const float pr = fast_exp2(s[r] * c - lv[e]);
-                        p[r] = pr;
-                        ds[r] = pr * (dpv[r] - dv[e]);
-                    }
-                }
-                const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
-                const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
-                {   // dS tile to the scratch as [key = lane & 31][query]; a key beyond N must not reach dQ
-                    const int kr = lane & 31;
-                    const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
-                    const u32x2 z = {0u, 0u};
-                    const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
-                                        kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
-#pragma unroll
-                    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
-                }
-                const bf16x8 qt00 = tr_frag(Qt, 0, 0, lane), qt10 = tr_frag(Qt, 1, 0, lane), qt01 = tr_frag(Qt, 0, 1, lane), qt11 = tr_frag(Qt, 1, 1, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot00, pf0, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot01, pf0, dv1, 0, 0, 0);
-                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot10, pf1, dv0, 0, 0, 0);
-                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot11, pf1, dv1, 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt00, sf0, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt01, sf0, dk1, 0, 0, 0);
-                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt10, sf1, dk0, 0, 0, 0);
-                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt11, sf1, dk1, 0, 0, 0);
+                pair_scores(QT + qs * TILE, OT + qs * TILE, LD + qs * 64);
+                pair_dvdk(QT + qs * TILE);
             }
             __syncthreads();                                   // every wave's dS of this step is in its scratch
             // ---- tile `st` of the next query block by LDS-DMA: waves 0..3 move 8-row pieces of Q and dO, wave 4 the (lse2, delta)
             // row.  Issued behind the step's first barrier: in step 0 the buffer it writes is the one the slower waves may
-            // still be flushing their dQ tiles through.
+            // still be flushing their dQ tiles through.  (Issuing a step earlier -- two tiles in step 0, none in the last, so
+            // that the wait before the block's last barrier never sees a fresh piece -- measured 6 % SLOWER.)
             if (st < tqn) {
                 const int wave_u = __builtin_amdgcn_readfirstlane(wave);
                 const int qt_next = (qb + 1) * OP_T + st;
@@ -792,27 +829,16 @@ __global__ __launch_bounds__(OP_T * 64) void attn_bwd_onepass_kernel(const bf16_
                     dma_b32(src, nq_lds + 2 * OP_T * TILE + st * 256);
                 }
             }
-            // dQ_(slot wave)^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query].  The scratch is free as soon as its
-            // fragments sit in registers: the step's second barrier comes right behind those reads, and the four dQ MFMAs (and
-            // the next step's operand reads) run past it -- not between two barriers as in the first version.
-            bf16x8 t0, t1;
+            // The scratch is free as soon as its fragments sit in registers: the step's second barrier comes right behind
+            // those reads, and the dQ MFMAs (and the next step's operand reads) run past it.
             if (do_q) {
                 const unsigned char* Sj = SC + jq * (32 * SCR);
                 t0 = tr_frag_scratch(Sj, 0, lane);
                 t1 = tr_frag_scratch(Sj, 1, lane);
             }
-            if (st == OP_T - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next block have landed
+            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next block have landed
             __syncthreads();                                   // the scratches are free again (last step: the next block is visible)
-            if (do_q) {
-                const unsigned char* Kj = KT + jq * TILE;
-                bf16x8 kq[4];
-                kq[0] = tr_frag(Kj, 0, 0, lane); kq[1] = tr_frag(Kj, 1, 0, lane); kq[2] = tr_frag(Kj, 0, 1, lane); kq[3] = tr_frag(Kj, 1, 1, lane);
-                __builtin_amdgcn_sched_barrier(0);
-                q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[0], t0, q0, 0, 0, 0);
-                q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[2], t0, q1, 0, 0, 0);
-                q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[1], t1, q0, 0, 0, 0);
-                q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kq[3], t1, q1, 0, 0, 0);
-            }
+            if (do_q) slot_dq(jq);
         }
         // ---- query slot `wave` has met every key tile of the strip: its dQ^T tile [64 d][32 queries] leaves the block.
         // Transposed through the finished query block's (now idle) Q buffer into row-contiguous form: one atomic
@@ -1043,12 +1069,15 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
         MOFO_CHECK_LAUNCH("mofo_attention_bwd(fused)");
         return MOFO_OK;
     }
-    static int two_pass = -1;
-    if (two_pass < 0) {
-        const char* e = getenv("MOFO_ATTN_BWD_TWO_PASS");
-        two_pass = e ? atoi(e) : 0;
+    // MOFO_ATTN_BWD_ONE_PASS=1: the one-pass form (5 MFMA products instead of 7, dQ by packed-bf16 atomics).  Measured at
+    // par with the two passes below (540 vs 567 + 19 us per ViT-B decoder layer alone, identical step time), so the default
+    // stays the deterministic, atomic-free two-pass form.
+    static int one_pass = -1;
+    if (one_pass < 0) {
+        const char* e = getenv("MOFO_ATTN_BWD_ONE_PASS");
+        one_pass = e ? atoi(e) : 0;
     }
-    if (!two_pass && lddqkv % 8 == 0 && ldqkv % 8 == 0) {
+    if (one_pass && lddqkv % 8 == 0 && ldqkv % 8 == 0) {
         rc = mofo_attention_delta_zero_dq(out, ldo, dout, lddo, B, N, H, delta, dqkv, lddqkv, stream);
         if (rc) return rc;
         return mofo_attention_bwd_onepass(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);

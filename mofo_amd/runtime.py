@@ -431,15 +431,16 @@ class PretrainRuntime:
             if n <= 160:
                 # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
                 ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
-            elif os.environ.get("MOFO_ATTN_BWD_TWO_PASS", "0") == "1":
-                # the former two-pass form (dQ pass + dK/dV pass, S and dP computed twice), kept for A/B timing
+            elif os.environ.get("MOFO_ATTN_BWD_ONE_PASS", "0") == "1":
+                # long sequences (the decoder): delta + cleared dq third, then ONE pass over the (query tile, key tile) pairs
+                # (5 MFMA products instead of 7; dQ strips meet through packed-bf16 atomics).  At par with the two passes in
+                # the step, so it is opt-in: the default stays atomic-free and deterministic.
+                ops.attention_delta_zero_dq(L.ao, S.dao, B, n, H, S.delta, T.dqkv)
+                ops.attention_bwd_onepass(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+            else:
                 ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
                 ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
                 ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-            else:
-                # long sequences (the decoder): delta + cleared dq third, then ONE pass over the (query tile, key tile) pairs
-                ops.attention_delta_zero_dq(L.ao, S.dao, B, n, H, S.delta, T.dqkv)
-                ops.attention_bwd_onepass(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
         self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY

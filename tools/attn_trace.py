@@ -9,13 +9,13 @@ usage: attn_trace.py <fwd|dq|fused> B N H
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-OUT = os.path.join(ROOT, "tools", "_trace", "libmofo_attn_trace.so")
+OUT = os.path.join(ROOT, "tools", "_trace", os.environ.get("MOFO_TRACE_LIB", "libmofo_attn_trace.so"))
 if "--build" in sys.argv:
     from mofo_amd import build as b
     b.build()
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    obj = os.path.join(os.path.dirname(OUT), "attn_trace.o")
-    subprocess.check_call([b.HIPCC] + b.FLAGS + ["-DMOFO_ATTN_TRACE", "-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
+    obj = OUT + ".o"
+    subprocess.check_call([b.HIPCC] + b.FLAGS + ([] if os.environ.get("MOFO_TRACE_NOSTAMP") else ["-DMOFO_ATTN_TRACE"]) + os.environ.get("MOFO_TRACE_DEFS", "").split() + ["-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
     objs = [obj] + [os.path.join(b.HERE, "build", s + ".o") for s in b.SOURCES if s != "attention.hip"]
     subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     print(OUT); sys.exit(0)
@@ -35,10 +35,14 @@ ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)
 ops.attention_delta(out, dout, B, N, H, delta)
 f = {"fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse),
      "dq": lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
-     "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta)}[kind]
+     "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta),
+     "onepass": lambda: ops.attention_bwd_onepass(qkv, dout, lse, delta, B, N, H, 0.125, dqkv)}[kind]
 names = ["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]
 if kind == "fused":   # N <= 160: the one-kernel backward
     names = ["issue loads + stage tiles + delta", "barrier", "step 0: pair (S, dP, dS, dV, dK)", "barrier", "step 0: dQ += K^T dS, barrier", "steps 1..T-1"]
+if kind == "onepass":   # N > 160: waves 0 and 4 (one SIMD's pair) of every block, query block 2, step 3
+    names = ["operand reads + S, dP MFMAs issued (8)", "exp / dS VALU, packs, scratch write, tr reads", "dV, dK MFMAs issued (8)",
+             "barrier 1 (every wave's dS written)", "scratch reads + barrier 2", "K^T reads + dQ MFMAs issued (4)"]
 for _ in range(5): f()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -47,11 +51,21 @@ for _ in range(20): f()
 e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) / 20 * 1e3
 print(f"{kind} B={B} N={N} H={H}: {us:.1f} us (trace build)")
+if os.environ.get("MOFO_TRACE_NOSTAMP"):
+    sys.exit(0)
 lib = _lib.load()
 buf = np.zeros((1 << 15) * 8, dtype=np.uint64)
 lib.mofo_debug_attn_trace_read.argtypes = [C.c_void_p, C.c_size_t]; lib.mofo_debug_attn_trace_read.restype = C.c_int
 assert lib.mofo_debug_attn_trace_read(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(-1, 8)
+if kind == "onepass":
+    both = buf.reshape(-1, 16)
+    both = both[both[:, 0] > 0].astype(np.int64)
+    for nm, o in (("wave 0", 0), ("wave 4", 8)):
+        dd = np.diff(both[:, o:o + 7], axis=1)
+        print(f"  {nm} phase medians: " + " ".join(f"{np.median(dd[:, i]):6.0f}" for i in range(6)))
+    print(f"wave 4 starts its step {np.median(both[:, 8] - both[:, 0]):.0f} clk after wave 0 (median); step length wave 0 "
+          f"{np.median(both[:, 6] - both[:, 0]):.0f}, wave 4 {np.median(both[:, 14] - both[:, 8]):.0f} clk")
 t = t[t[:, 0] > 0][:, :7].astype(np.int64)
 d = np.diff(t, axis=1)
 print(f"{len(t)} blocks")
