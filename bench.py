@@ -241,7 +241,7 @@ def main():
         warm = full.summary()
         names = {("gemm", 0, 0): "gemm_nt_bf16", ("gemm", 0, 1): "gemm_nt_bias_gelu", ("gemm", 0, 2): "gemm_nt_resid_f32",
                  ("gemm", 0, 3): "gemm_nt_pos_f32", ("gemm", 1, 0): "gemm_nn_bf16", ("gemm", 1, 4): "gemm_nn_dgelu",
-                 ("gemm", 2, 5): "gemm_tn_wgrad_f32"}
+                 ("gemm", 2, 5): "gemm_tn_wgrad_f32", ("gemm", 0, 6): "gemm_nt_resid_bf16", ("gemm", 0, 7): "gemm_nt_pos_bf16"}
         mfma_keys = [k for k in summ if k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv", "attn_bwd_1p")]
         total_ms = sum(v["ms"] for v in warm.values()) / max(1, n_instr) * args.steps
         dom = max(summ, key=lambda k: summ[k]["ms"])

@@ -35,7 +35,9 @@ enum { MOFO_EPI_BF16 = 0,       /* C(bf16) = acc (+bias[n])                     
        MOFO_EPI_RESID_F32 = 2,  /* C(f32) = resid(f32) + acc (+bias)   (proj / fc2 + residual add)      */
        MOFO_EPI_POS_F32 = 3,    /* C(f32)[rowmap(m)] = acc (+bias) + pos[row_idx[m]]  (patch-embed / e2d)*/
        MOFO_EPI_DGELU_BF16 = 4, /* C(bf16) = acc * gelu_erf'(aux[m,n])   (backward through nn.GELU)     */
-       MOFO_EPI_F32 = 5         /* C(f32) = acc, or += (atomic) when splits>1 or accumulate!=0          */ };
+       MOFO_EPI_F32 = 5,        /* C(f32) = acc, or += (atomic) when splits>1 or accumulate!=0          */
+       MOFO_EPI_RESID_BF16 = 6, /* C(bf16) = aux(bf16)[m,n] + acc (+bias): residual add on a bf16 residual stream (decoder) */
+       MOFO_EPI_POS_BF16 = 7    /* POS_F32 with a bf16 destination (the decoder's bf16 input stream)    */ };
 typedef struct mofo_gemm_args {
     int op, epilogue;
     int M, N, K;                  /* C is MxN, reduction length K */
@@ -45,7 +47,7 @@ typedef struct mofo_gemm_args {
     void* C2; int ldc2;           /* BIAS_GELU second output */
     const float* bias;            /* [N] or NULL */
     const float* resid; int ldr;  /* RESID_F32 */
-    const void* aux; int ldaux;   /* DGELU: pre-activation h (bf16) */
+    const void* aux; int ldaux;   /* DGELU: pre-activation h (bf16); RESID_BF16: the residual (bf16) */
     const float* pos; int ldpos;  /* POS_F32: table rows */
     const int* row_idx;           /* POS_F32: [M] table row per output row */
     int rows_in, rows_out, row_off; /* POS_F32: out row = (m / rows_in) * rows_out + row_off + m % rows_in */
@@ -63,14 +65,15 @@ int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* str
 
 /* ---- LayerNorm (eps inside sqrt, biased variance): modeling_finetune.py:200,206,218-219; modeling_pretrain.py:51,95,123,157.
  * Row r of the (M x D) problem reads/writes x row  (r / rows_in) * rows_out + row_off + r % rows_in  (pass rows_in=M,
- * rows_out=M, row_off=0 for the identity map; the decoder's final norm uses the last N_mask rows of every clip). ---- */
-int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float eps, int M, int D,
+ * rows_out=M, row_off=0 for the identity map; the decoder's final norm uses the last N_mask rows of every clip). ----
+ * x (the residual stream) is f32, or bf16 when x_is_bf16 != 0 (the decoder's stream). */
+int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
 /* dx = dres + LN'(dy).  The incoming residual-stream gradient is dres (f32) OR dres_bf16 (bf16) OR neither; the result
  * goes to dx (f32) and/or dx_bf16 (at least one).  dw/db accumulate (+=): with partial_ws the per-block partials are stored
  * and summed by a second tiny kernel (one writer per address, deterministic); without it every block adds atomically. */
-int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const float* x, int ldx, const float* w,
+int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf16, int ldx, const float* w,
                        const float* mean, const float* rstd, const float* dres, int lddres, int M, int D,
                        int rows_in, int rows_out, int row_off,
                        float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db,
@@ -128,10 +131,10 @@ int mofo_ingest_u8(const uint8_t* frames, int B, int T, int H, int W, float* cli
 int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int pt, int p,
                       const int* tok_idx, int n_tok, void* out_bf16, int ldo, void* stream);
 
-/* ---- decoder input assembly: modeling_pretrain.py:260-263.  Writes the masked half of x_full (f32 [B,N,D]):
- * x_full[b, n_vis + j] = mask_token + pos[msk_idx[b,j]]  (the visible half is the e2d GEMM's POS_F32 epilogue). ---- */
+/* ---- decoder input assembly: modeling_pretrain.py:260-263.  Writes the masked half of x_full ([B,N,D], f32 or bf16):
+ * x_full[b, n_vis + j] = mask_token + pos[msk_idx[b,j]]  (the visible half is the e2d GEMM's POS_F32 / POS_BF16 epilogue). ---- */
 int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx,
-                          int B, int N, int n_vis, int D, float* x_full, void* stream);
+                          int B, int N, int n_vis, int D, void* x_full, int x_is_bf16, void* stream);
 /* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows.
  * dx_full is f32 (dx_is_bf16 = 0) or bf16 (1). */
 int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token, void* stream);

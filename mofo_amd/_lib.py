@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libmofo_hip.so")
 
 # enums (mirror include/mofo_hip.h)
 GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
-EPI_BF16, EPI_BIAS_GELU, EPI_RESID_F32, EPI_POS_F32, EPI_DGELU_BF16, EPI_F32 = 0, 1, 2, 3, 4, 5
+EPI_BF16, EPI_BIAS_GELU, EPI_RESID_F32, EPI_POS_F32, EPI_DGELU_BF16, EPI_F32, EPI_RESID_BF16, EPI_POS_BF16 = 0, 1, 2, 3, 4, 5, 6, 7
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
 
@@ -32,8 +32,8 @@ _SIGS = {
     "mofo_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
-    "mofo_layernorm_fwd": (_i, [_vp, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
-    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mofo_layernorm_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mofo_layernorm_bwd_blocks": (_i, [_i]),
     "mofo_layernorm_bwd_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),
@@ -46,7 +46,7 @@ _SIGS = {
     "mofo_attention_bwd_onepass": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mofo_patch_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
-    "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "mofo_patch_gather_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mofo_target_mse_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),

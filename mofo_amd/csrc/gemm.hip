@@ -163,7 +163,8 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
     (void)stamp;
     constexpr int WROWS = 16 * MI;              // rows of the wave tile
     constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
-    constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16);
+    constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16);
+    constexpr bool AUX_ROWS = (EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16);   // a bf16 [M,N] operand read in the epilogue
 
     auto stage_acc = [&](int ps) {
 #pragma unroll
@@ -193,7 +194,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
         auto run = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             u32x4 h[NG];
-            if constexpr (EPI == MOFO_EPI_DGELU_BF16) {
+            if constexpr (AUX_ROWS) {
 #pragma unroll
                 for (int g = 0; g < NG; ++g) {
                     const int m = mb + g * 8 + (lane >> 3);
@@ -221,6 +222,10 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                         if (q < 2) { v0[2 * q] *= d[0]; v0[2 * q + 1] *= d[1]; }
                         else       { v1[2 * q - 4] *= d[0]; v1[2 * q - 3] *= d[1]; }
                     }
+                }
+                if constexpr (EPI == MOFO_EPI_RESID_BF16) {   // residual add on the bf16 residual stream
+                    v0 += f32x4{bf16lo_to_f32(h[g][0]), bf16hi_to_f32(h[g][0]), bf16lo_to_f32(h[g][1]), bf16hi_to_f32(h[g][1])};
+                    v1 += f32x4{bf16lo_to_f32(h[g][2]), bf16hi_to_f32(h[g][2]), bf16lo_to_f32(h[g][3]), bf16hi_to_f32(h[g][3])};
                 }
                 const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
                 const bool ok = FULL || (ncol && m < p.M);
@@ -294,13 +299,17 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                 size_t orow = m;
                 if constexpr (EPI == MOFO_EPI_RESID_F32) {
                     v += rr[(g / CH) & 1][g % CH];
-                } else if constexpr (EPI == MOFO_EPI_POS_F32) {
+                } else if constexpr (EPI == MOFO_EPI_POS_F32 || EPI == MOFO_EPI_POS_BF16) {
                     if (ok) {
                         orow = (size_t)(m / p.rows_in) * p.rows_out + p.row_off + (m % p.rows_in);
                         v += *(const f32x4*)(p.pos + (size_t)p.row_idx[m] * p.ldpos + n);
                     }
                 }
-                if (ok) *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+                if constexpr (EPI == MOFO_EPI_POS_BF16) {
+                    if (ok) *(u32x2*)((bf16_t*)p.C + orow * p.ldc + n) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                } else {
+                    if (ok) *(f32x4*)((float*)p.C + orow * p.ldc + n) = v;
+                }
             }
             __builtin_amdgcn_wave_barrier();
         };
@@ -727,7 +736,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         const GemmP& p = g.p[0];
         const int total = g.start[1];
         // persistent form: one problem, no split-K / accumulate
-        const bool can_persist = g.count == 1 && !p.atomic && p.k_per_split >= p.K && EPI != MOFO_EPI_POS_F32;
+        const bool can_persist = g.count == 1 && !p.atomic && p.k_per_split >= p.K && EPI != MOFO_EPI_POS_F32 && EPI != MOFO_EPI_POS_BF16;
         int var = forced >= 0 ? forced : ((EPI == MOFO_EPI_RESID_F32 && total <= 768) || !can_persist ? 0 : 2);
         if (var == 2 && !can_persist) var = 1;
         // grids of at most two 64-row tiles per CU with a reduction worth splitting: in-block split-K (VAR 3)
@@ -774,14 +783,16 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
     if (op == MOFO_GEMM_NT && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_NN && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NN: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_TN && a->M % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm TN: M=%d must be a multiple of 8", a->M);
-    const bool out_bf16 = (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_DGELU_BF16);
+    const bool out_bf16 = (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_DGELU_BF16 || epi == MOFO_EPI_RESID_BF16 ||
+                           epi == MOFO_EPI_POS_BF16);
     if (a->ldc % (out_bf16 ? 8 : 4)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: ldc must be a multiple of %d", out_bf16 ? 8 : 4);
     int splits = a->splits < 1 ? 1 : a->splits;
     if (splits > 1 && epi != MOFO_EPI_F32) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: split-K only with the f32 accumulate epilogue");
     if (epi == MOFO_EPI_BIAS_GELU && (!a->C2 || a->ldc2 % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: BIAS_GELU needs C2 (ldc2 multiple of 8)");
     if (epi == MOFO_EPI_RESID_F32 && (!a->resid || a->ldr % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_F32 needs resid (ldr multiple of 4)");
     if (epi == MOFO_EPI_DGELU_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: DGELU needs aux (ldaux multiple of 8)");
-    if (epi == MOFO_EPI_POS_F32 && (!a->pos || !a->row_idx || a->rows_in <= 0 || a->ldpos % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
+    if (epi == MOFO_EPI_RESID_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_BF16 needs the bf16 residual in aux (ldaux multiple of 8)");
+    if ((epi == MOFO_EPI_POS_F32 || epi == MOFO_EPI_POS_BF16) && (!a->pos || !a->row_idx || a->rows_in <= 0 || a->ldpos % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
     {
         // the operands are addressed through 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets):
         // an operand image of 2 GiB or more is refused instead of wrapping (split the rows / the reduction on the caller's side)
@@ -844,6 +855,8 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
             case MOFO_EPI_BIAS_GELU: GO(OPL_ROW, OPL_ROW, MOFO_EPI_BIAS_GELU);
             case MOFO_EPI_RESID_F32: GO(OPL_ROW, OPL_ROW, MOFO_EPI_RESID_F32);
             case MOFO_EPI_POS_F32: GO(OPL_ROW, OPL_ROW, MOFO_EPI_POS_F32);
+            case MOFO_EPI_POS_BF16: GO(OPL_ROW, OPL_ROW, MOFO_EPI_POS_BF16);
+            case MOFO_EPI_RESID_BF16: GO(OPL_ROW, OPL_ROW, MOFO_EPI_RESID_BF16);
             case MOFO_EPI_F32: GO(OPL_ROW, OPL_ROW, MOFO_EPI_F32);
         }
     } else if (op == MOFO_GEMM_NN) {
@@ -884,7 +897,8 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
             const char* e8 = getenv("MOFO_GEMM_MI8");
             mi8 = e8 ? atoi(e8) : -1;
         }
-        if (mi != 2 && mi8 != 0 && count == 1 && a[0].splits <= 1 && !a[0].accumulate && a[0].epilogue != MOFO_EPI_POS_F32) {
+        if (mi != 2 && mi8 != 0 && count == 1 && a[0].splits <= 1 && !a[0].accumulate && a[0].epilogue != MOFO_EPI_POS_F32 &&
+            a[0].epilogue != MOFO_EPI_POS_BF16) {
             const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, BN);
             const double eff4 = (double)t128 / (double)(ceil_div((int)t128, 768) * 768);
             const double eff8 = (double)t256 / (double)(ceil_div((int)t256, 512) * 512);

@@ -12,21 +12,30 @@ __device__ __forceinline__ size_t map_row(int r, int rows_in, int rows_out, int 
     return (size_t)(r / rows_in) * rows_out + row_off + (r % rows_in);
 }
 
-template <int NIT>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+// XB: the residual stream is bf16 (the decoder, runtime.py) instead of f32: 8-byte loads of four elements per lane.
+template <int NIT, bool XB>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv_, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps, int M, int D, int rows_in,
                                                       int rows_out, int row_off, bf16_t* __restrict__ y, int ldy,
                                                       float* __restrict__ mean, float* __restrict__ rstd) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= M) return;
-    const float* xr = x + map_row(r, rows_in, rows_out, row_off) * ldx;
+    const size_t xrow = map_row(r, rows_in, rows_out, row_off) * ldx;
     f32x4 v[NIT];
     float s = 0.f;
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = (it * 64 + lane) * 4;
-        v[it] = c < D ? *(const f32x4*)(xr + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        v[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < D) {
+            if constexpr (XB) {
+                const u32x2 t = *(const u32x2*)((const bf16_t*)xv_ + xrow + c);
+                v[it] = f32x4{bf16lo_to_f32(t[0]), bf16hi_to_f32(t[0]), bf16lo_to_f32(t[1]), bf16hi_to_f32(t[1])};
+            } else {
+                v[it] = *(const f32x4*)((const float*)xv_ + xrow + c);
+            }
+        }
         s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
     }
     const float mu = wave_sum(s) / D;
@@ -65,8 +74,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 
 // Two rows per wave per iteration: both rows' loads are issued before either row's shuffle reductions, so the HBM
 // latency of one row hides behind the arithmetic of the other (the one-row form ran at 2-2.8 TB/s in the step).
-template <int NIT>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const float* __restrict__ x,
+template <int NIT, bool XB>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ dy, int lddy, const void* __restrict__ xv_,
                                                       int ldx, const float* __restrict__ w, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
                                                       int lddres, int M, int D, int rows_in, int rows_out, int row_off,
@@ -101,7 +110,12 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             for (int it = 0; it < NIT; ++it) {
                 const int c = (it * 64 + lane) * 4;
                 if (c < D) {
-                    xv[k][it] = *(const f32x4*)(x + xr[k] * ldx + c);
+                    if constexpr (XB) {
+                        const u32x2 t = *(const u32x2*)((const bf16_t*)xv_ + xr[k] * ldx + c);
+                        xv[k][it] = f32x4{bf16lo_to_f32(t[0]), bf16hi_to_f32(t[0]), bf16lo_to_f32(t[1]), bf16hi_to_f32(t[1])};
+                    } else {
+                        xv[k][it] = *(const f32x4*)((const float*)xv_ + xr[k] * ldx + c);
+                    }
                     dv[k][it] = *(const u32x2*)(dy + (size_t)rr[k] * lddy + c);
                     if (dresb) {   // residual-stream gradient kept in bf16 (one tensor instead of an f32 + a bf16 copy)
                         const u32x2 rb = *(const u32x2*)(dresb + xr[k] * lddresb + c);
@@ -289,7 +303,7 @@ static int ln_check(const char* who, int M, int D, int rows_in, int rows_out) {
     return MOFO_OK;
 }
 
-extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const float* b, float eps, int M, int D,
+extern "C" int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
                                   int rows_in, int rows_out, int row_off, void* y, int ldy, float* mean, float* rstd,
                                   void* stream) {
     if (!x || !w || !b || !y || !mean || !rstd) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_fwd: null pointer");
@@ -299,7 +313,8 @@ extern "C" int mofo_layernorm_fwd(const float* x, int ldx, const float* w, const
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
     dim3 grid(ceil_div(M, 4)), block(256);
-#define GO(N_) hipLaunchKernelGGL((ln_fwd_kernel<N_>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd)
+#define GO(N_) do { if (x_is_bf16) hipLaunchKernelGGL((ln_fwd_kernel<N_, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd); \
+                    else hipLaunchKernelGGL((ln_fwd_kernel<N_, false>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd); } while (0)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_fwd");
@@ -311,7 +326,7 @@ extern "C" int mofo_layernorm_bwd_blocks(int M) {
     return blocks > 1024 ? 1024 : (blocks < 1 ? 1 : blocks);
 }
 
-extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int ldx, const float* w, const float* mean,
+extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const void* x, int x_is_bf16, int ldx, const float* w, const float* mean,
                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
                                   int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
                                   const void* dresb, int lddresb, float* partial_ws, void* stream) {
@@ -329,8 +344,10 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const float* x, int 
     // at the encoder's M = 5120 while bounding the atomic traffic (1024 blocks x 2 D floats)
     const int blocks = mofo_layernorm_bwd_blocks(M);
     dim3 grid(blocks), block(256);
-#define GO(N_) hipLaunchKernelGGL((ln_bwd_kernel<N_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws)
+#define GO_(N_, XB_) hipLaunchKernelGGL((ln_bwd_kernel<N_, XB_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws)
+#define GO(N_) do { if (x_is_bf16) GO_(N_, true); else GO_(N_, false); } while (0)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
+#undef GO_
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_bwd");
     if (partial_ws && !defer) {

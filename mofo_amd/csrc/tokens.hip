@@ -119,19 +119,21 @@ __global__ __launch_bounds__(256) void patch_gather_kernel(SRC src, int pt, int 
 }
 
 // ---------------------------------------------------------------------------------------------- decoder assembly
+template <bool OUTB>   // OUTB: the decoder's input stream is bf16
 __global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict__ mask_token, const float* __restrict__ pos,
                                                         int ldpos, const int* __restrict__ msk_idx, int N, int n_vis, int D,
-                                                        int rows, float* __restrict__ x_full) {
+                                                        int rows, void* __restrict__ x_full) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
     if (row >= rows) return;
     const int n_msk = N - n_vis;
     const int b = row / n_msk, j = row - b * n_msk;
     const float* pr = pos + (size_t)msk_idx[row] * ldpos;
-    float* dst = x_full + ((size_t)b * N + n_vis + j) * D;
+    const size_t drow = ((size_t)b * N + n_vis + j) * D;
     for (int c = lane * 4; c < D; c += 256) {
         const f32x4 v = *(const f32x4*)(mask_token + c) + *(const f32x4*)(pr + c);
-        *(f32x4*)(dst + c) = v;
+        if constexpr (OUTB) *(u32x2*)((bf16_t*)x_full + drow + c) = u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+        else *(f32x4*)((float*)x_full + drow + c) = v;
     }
 }
 
@@ -302,12 +304,16 @@ extern "C" int mofo_patch_gather_u8(const uint8_t* frames, int B, int T, int H, 
 }
 
 extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx, int B, int N,
-                                     int n_vis, int D, float* x_full, void* stream) {
+                                     int n_vis, int D, void* x_full, int x_is_bf16, void* stream) {
     if (!mask_token || !pos || !msk_idx || !x_full) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: null pointer");
     if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || ldpos % 4) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: bad sizes");
     const int rows = B * (N - n_vis);
-    hipLaunchKernelGGL(fill_mask_kernel, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
-                       msk_idx, N, n_vis, D, rows, x_full);
+    if (x_is_bf16)
+        hipLaunchKernelGGL(fill_mask_kernel<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
+                           msk_idx, N, n_vis, D, rows, x_full);
+    else
+        hipLaunchKernelGGL(fill_mask_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
+                           msk_idx, N, n_vis, D, rows, x_full);
     MOFO_CHECK_LAUNCH("mofo_fill_mask_tokens");
     return MOFO_OK;
 }

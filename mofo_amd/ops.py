@@ -8,8 +8,8 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import (EPI_BF16, EPI_BIAS_GELU, EPI_DGELU_BF16, EPI_F32, EPI_POS_F32, EPI_RESID_F32, GEMM_NN, GEMM_NT,
-                   GEMM_TN, GemmArgs)
+from ._lib import (EPI_BF16, EPI_BIAS_GELU, EPI_DGELU_BF16, EPI_F32, EPI_POS_BF16, EPI_POS_F32, EPI_RESID_BF16, EPI_RESID_F32,
+                   GEMM_NN, GEMM_NT, GEMM_TN, GemmArgs)
 
 BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
 
@@ -141,9 +141,9 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         raise ValueError(f"reduction mismatch: {tuple(A.shape)} vs {tuple(B.shape)} for op {op}")
     out_dtype = F32 if epi in (EPI_RESID_F32, EPI_POS_F32, EPI_F32) else BF16
     _chk(C_, out_dtype, "C", 2)
-    if epi != EPI_POS_F32 and tuple(C_.shape) != (M, N):
+    if epi not in (EPI_POS_F32, EPI_POS_BF16) and tuple(C_.shape) != (M, N):
         raise ValueError(f"C must be {(M, N)}, got {tuple(C_.shape)}")
-    if epi == EPI_POS_F32:
+    if epi in (EPI_POS_F32, EPI_POS_BF16):
         _chk(pos, F32, "pos", 2), _chk(row_idx, I32, "row_idx")
         if row_idx.numel() != M or pos.shape[1] != N or C_.shape[1] != N or rows_in <= 0:
             raise ValueError("POS_F32: row_idx must have M entries, pos/C must have N columns")
@@ -161,7 +161,7 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         _chk(resid, F32, "resid", 2)
         if tuple(resid.shape) != (M, N):
             raise ValueError("resid shape")
-    if epi == EPI_DGELU_BF16:
+    if epi in (EPI_DGELU_BF16, EPI_RESID_BF16):
         _chk(aux, BF16, "aux", 2)
         if tuple(aux.shape) != (M, N):
             raise ValueError("aux shape")
@@ -182,9 +182,9 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         nbytes += 2.0 * M * N
     elif epi == EPI_RESID_F32:
         nbytes += resid.element_size() * M * N
-    elif epi == EPI_DGELU_BF16:
+    elif epi in (EPI_DGELU_BF16, EPI_RESID_BF16):
         nbytes += 2.0 * M * N
-    elif epi == EPI_POS_F32:
+    elif epi in (EPI_POS_F32, EPI_POS_BF16):
         nbytes += 4.0 * M * N
     return a, 2.0 * M * N * K, nbytes
 
@@ -198,7 +198,10 @@ def colsum_bf16(X, out):
 
 
 def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=None, row_off=0):
-    _chk(x, F32, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(y, BF16, "y", 2), _chk(mean, F32, "mean", 1), _chk(rstd, F32, "rstd", 1)
+    """``x``: the residual stream, f32 or bf16 (the decoder's)"""
+    if x is None or x.dtype not in (F32, BF16):
+        raise TypeError("x must be f32 or bf16")
+    _chk(x, x.dtype, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(y, BF16, "y", 2), _chk(mean, F32, "mean", 1), _chk(rstd, F32, "rstd", 1)
     D = x.shape[1]
     M = y.shape[0] if M is None else M
     rows_in = M if rows_in is None else rows_in
@@ -207,15 +210,18 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
         raise ValueError("layernorm_fwd: shape mismatch")
     if M % rows_in or (M // rows_in - 1) * rows_out + row_off + rows_in > x.shape[0]:
         raise ValueError("layernorm_fwd: row map exceeds x")
-    _run("mofo_layernorm_fwd", ("ln_fwd",), 6.0 * M * D, _p(x), _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off, _p(y), _ld(y),
-         _p(mean), _p(rstd))
+    xb = 1 if x.dtype == BF16 else 0
+    _run("mofo_layernorm_fwd", ("ln_fwd",), (4.0 if xb else 6.0) * M * D, _p(x), xb, _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off,
+         _p(y), _ld(y), _p(mean), _p(rstd))
     return y
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):
     """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
     (bf16) are the outputs, either may be None but not both."""
-    _chk(dy, BF16, "dy", 2), _chk(x, F32, "x", 2), _chk(w, F32, "w", 1)
+    if x is None or x.dtype not in (F32, BF16):
+        raise TypeError("x must be f32 or bf16")
+    _chk(dy, BF16, "dy", 2), _chk(x, x.dtype, "x", 2), _chk(w, F32, "w", 1)
     defer = dw is None and db is None
     if defer:
         if partial_ws is None:
@@ -252,10 +258,11 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         _chk(partial_ws, F32, "partial_ws", 1)
         if partial_ws.numel() < 2 * 1024 * D:
             raise ValueError("partial_ws must hold 2*1024*D floats")
-    bytes_ = (6.0 + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
+    xb = 1 if x.dtype == BF16 else 0
+    bytes_ = ((4.0 if xb else 6.0) + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
               + (2.0 if dxb is not None else 0.0)) * M * D
     _run("mofo_layernorm_bwd", ("ln_bwd",), bytes_,
-         _p(dy), _ld(dy), _p(x), _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
+         _p(dy), _ld(dy), _p(x), xb, _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
          rows_in, rows_out, row_off, _p(dx), _ld(dx) if dx is not None else 0, _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
          _p(dres_b), _ld(dres_b) if dres_b is not None else 0, _p(partial_ws))
     return _lib.load().mofo_layernorm_bwd_blocks(M) if defer else None
@@ -388,11 +395,15 @@ def patch_gather_u8(frames, pt, p, tok_idx, out):
 
 
 def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
-    _chk(mask_token, F32, "mask_token"), _chk(pos, F32, "pos", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(x_full, F32, "x_full", 3)
+    if x_full is None or x_full.dtype not in (F32, BF16):
+        raise TypeError("x_full must be f32 or bf16")
+    _chk(mask_token, F32, "mask_token"), _chk(pos, F32, "pos", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(x_full, x_full.dtype, "x_full", 3)
     B, N, D = x_full.shape
     if not x_full.is_contiguous() or mask_token.numel() != D or pos.shape[1] != D or msk_idx.shape != (B, N - n_vis) or pos.shape[0] < N:
         raise ValueError("fill_mask_tokens: shape mismatch")
-    _run("mofo_fill_mask_tokens", ("fill_mask",), 8.0 * B * (N - n_vis) * D, _p(mask_token), _p(pos), _ld(pos), _p(msk_idx), B, N, n_vis, D, _p(x_full))
+    xb = 1 if x_full.dtype == BF16 else 0
+    _run("mofo_fill_mask_tokens", ("fill_mask",), (6.0 if xb else 8.0) * B * (N - n_vis) * D, _p(mask_token), _p(pos), _ld(pos), _p(msk_idx), B, N, n_vis, D,
+         _p(x_full), xb)
 
 
 def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):

@@ -230,6 +230,11 @@ class PretrainRuntime:
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
         # forward_only: the fine-tune / feature-extraction forward (modeling_finetune.py) -- no gradient buckets to plan
         self.segments = [] if forward_only else self.plan_segments()
+        # The DECODER's residual stream is kept in bf16 (x_full, x_mid, x_out): its GEMMs reduce over 384 / 1536 and are bound
+        # by HBM, and the f32 stream cost 16 B per token element and block in residual epilogues and LayerNorm reads (1.2 GB
+        # per ViT-B B=32 step).  The encoder's stream (5 120 token rows, latency-bound kernels) stays f32.  MOFO_DEC_RESID=f32
+        # restores the f32 decoder stream (A/B, parity debugging).
+        self.dec_resid = F32 if os.environ.get("MOFO_DEC_RESID", "bf16") == "f32" else BF16
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
@@ -274,13 +279,13 @@ class PretrainRuntime:
                                          "attn.proj.bias", "norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias")])
 
     # ------------------------------------------------------------------ workspace
-    def _block_ws(self, M, D, H, B, n):
+    def _block_ws(self, M, D, H, B, n, resid=F32):
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         return NS(xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * H * n, dt=F32),
-                  x_mid=e(M, D, dt=F32), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
-                  x_out=e(M, D, dt=F32))
+                  x_mid=e(M, D, dt=resid), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
+                  x_out=e(M, D, dt=resid))
 
     def _scratch(self, M, D, H, B, n):
         dev = self.dev
@@ -328,8 +333,8 @@ class PretrainRuntime:
         if self.dec_prefix is not None:
             Md = B * N
             w.Md = Md
-            w.x_full = e(B, N, d.dec_dim, dt=F32)
-            w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N) for _ in range(d.dec_depth)]
+            w.x_full = e(B, N, d.dec_dim, dt=self.dec_resid)
+            w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N, self.dec_resid) for _ in range(d.dec_depth)]
             w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N)
             if n_vis is not None:
                 Mm = B * (N - n_vis)
@@ -373,10 +378,16 @@ class PretrainRuntime:
         ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
         ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse)
-        ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
+        if L.x_mid.dtype == BF16:      # bf16 residual stream (decoder): the residual rides in the GEMM's `aux` operand
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.ao, W.proj, L.x_mid, bias=W.projb, aux=x_in)
+        else:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
         ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
         ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
-        ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
+        if L.x_out.dtype == BF16:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.g, W.fc2, L.x_out, bias=W.fc2b, aux=L.x_mid)
+        else:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
         return L.x_out
 
     def _wgrad(self, dY, X, G, bias_grad=None):
@@ -390,7 +401,10 @@ class PretrainRuntime:
         chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
         R = problems[0][0].shape[0]
         tiles = sum(((pr[0].shape[1] + 127) // 128) * ((pr[1].shape[1] + 127) // 128) for pr in problems)
-        thr, target = int(os.environ.get("MOFO_WGRAD_THR", "200")), int(os.environ.get("MOFO_WGRAD_TARGET", "400"))
+        # a group below `thr` tiles is split along the token reduction until it has ~`target` blocks: 756 = 3 resident blocks on
+        # each of 252 CUs (the decoder's 108 tiles x 7 splits; 4 splits / 432 blocks left most CUs with one or two blocks and
+        # their load -> MFMA latency chains uncovered: 242 -> 228 us per launch alone)
+        thr, target = int(os.environ.get("MOFO_WGRAD_THR", "200")), int(os.environ.get("MOFO_WGRAD_TARGET", "756"))
         splits = 1 if tiles >= thr else int(max(1, min(-(-target // tiles), 16, R // 1024)))
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
@@ -600,7 +614,8 @@ class PretrainRuntime:
     def bridge_forward(self, w: NS, enc_out_bf16: torch.Tensor):
         """modeling_pretrain.py:256-263: encoder_to_decoder (no bias) + pos for the visible half, mask_token + pos for the rest."""
         d, s = self.d, self.store
-        ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, enc_out_bf16, s.bview("encoder_to_decoder.weight"), w.x_full.view(w.Md, d.dec_dim),
+        ops.gemm(ops.GEMM_NT, ops.EPI_POS_BF16 if w.x_full.dtype == BF16 else ops.EPI_POS_F32, enc_out_bf16,
+                 s.bview("encoder_to_decoder.weight"), w.x_full.view(w.Md, d.dec_dim),
                  pos=self.pos_dec, row_idx=w.vis_idx.view(-1), rows_in=w.n_vis, rows_out=w.N, row_off=0)
         ops.fill_mask_tokens(s.view("mask_token").view(-1), self.pos_dec, w.msk_idx, w.n_vis, w.x_full)
         return w.x_full
@@ -614,7 +629,8 @@ class PretrainRuntime:
 
     # ------------------------------------------------------------------ decoder
     def decoder_forward(self, w: NS, x_full: torch.Tensor, n_ret: int):
-        """modeling_pretrain.py:152-161; x_full fp32 [B, N, dec_dim]; returns bf16 predictions [B*n_ret, patch_out]."""
+        """modeling_pretrain.py:152-161; x_full [B, N, dec_dim] (bf16, or f32 with MOFO_DEC_RESID=f32); returns bf16
+        predictions [B*n_ret, patch_out]."""
         d, s, p = self.d, self.store, self.dec_prefix
         x = x_full.view(w.Md, d.dec_dim)
         for W, L in zip(self.decW, w.dec):

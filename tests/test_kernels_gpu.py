@@ -65,6 +65,10 @@ def test_gemm_nt_epilogues(dev, M, N, K):
     Cf = torch.empty(M, N, dtype=F32, device=dev)
     ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, B, Cf, bias=bias, resid=R)
     assert _rel(Cf, h + R) < 1e-5 + 1e-6 * math.sqrt(K)
+    # residual add on a bf16 residual stream (the decoder): residual in `aux`, bf16 out
+    Rb = R.to(BF16)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, A, B, Cb, bias=bias, aux=Rb)
+    assert _rel(Cb, h + Rb.float()) < 6e-3
     # f32 plain, split-K with atomics, accumulate
     ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf)
     assert _rel(Cf, ref) < 1e-5
@@ -91,6 +95,11 @@ def test_gemm_nt_pos_rowmap(dev):
     got = out.view(Bc, Ntok, N)
     assert _rel(got[:, :nv], ref) < 1e-5
     assert torch.all(got[:, nv:] == -7.0)      # rows outside the map untouched
+    outb = torch.full((Bc * Ntok, N), -7.0, dtype=BF16, device=dev)   # the same into a bf16 stream
+    ops.gemm(ops.GEMM_NT, ops.EPI_POS_BF16, A, W, outb, bias=bias, pos=pos, row_idx=idx.flatten(), rows_in=nv, rows_out=Ntok, row_off=0)
+    gb = outb.view(Bc, Ntok, N)
+    assert torch.equal(gb[:, :nv], ref.to(BF16)) or _rel(gb[:, :nv], ref) < 3e-3
+    assert torch.all(gb[:, nv:] == -7.0)
 
 
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (320, 768, 2304), (77, 128, 192), (640, 3072, 768), (50, 64, 256), (200, 136, 1600), (5000, 3064, 128)])
@@ -249,6 +258,20 @@ def test_layernorm_fwd_bwd(dev, M, D):
     ops.layernorm_bwd(dy, x, w, mean, rstd, dres_b, None, dxb, dw, db, partial_ws=ws)
     assert _rel(dxb, xr.grad + dres_b.float()) < 4e-3
     assert _rel(dw - 0.25, wr.grad) < 1e-4 and _rel(db + 0.5, br.grad) < 1e-4
+    # bf16 residual stream (the decoder): x itself is bf16; same arithmetic on the rounded input
+    xb = x.to(BF16)
+    xq = xb.float().requires_grad_(True)
+    yq = torch.nn.functional.layer_norm(xq, (D,), wr, br, 1e-6)
+    ops.layernorm_fwd(xb, w, b, 1e-6, y, mean, rstd)
+    assert _rel(y, yq) < 4e-3
+    assert torch.allclose(mean, xb.float().mean(1), atol=1e-5, rtol=1e-5)
+    wr.grad = None
+    br.grad = None
+    yq.backward(dy.float())
+    dw.zero_(), db.zero_()
+    ops.layernorm_bwd(dy, xb, w, mean, rstd, dres_b, None, dxb, dw, db, partial_ws=ws)
+    assert _rel(dxb, xq.grad + dres_b.float()) < 4e-3
+    assert _rel(dw, wr.grad) < 1e-4 and _rel(db, br.grad) < 1e-4
 
 
 def test_layernorm_bwd_deferred_grouped_finalize(dev):
@@ -537,6 +560,9 @@ def test_assemble_fwd_bwd(dev):
     ops.fill_mask_tokens(tok, pos, msk, nv, xf)
     assert torch.all(xf[:, :nv] == 3.0)
     assert torch.equal(xf[:, nv:], (tok + pos[msk.long()]))
+    xfb = torch.full((Bc, N, D), 3.0, dtype=BF16, device=dev)           # bf16 decoder stream
+    ops.fill_mask_tokens(tok, pos, msk, nv, xfb)
+    assert torch.all(xfb[:, :nv] == 3.0) and torch.equal(xfb[:, nv:], (tok + pos[msk.long()]).to(BF16))
     dx = _rand((Bc, N, D), dev, 3, 1.0, F32)
     de = torch.empty(Bc * nv, D, dtype=BF16, device=dev)
     dt = torch.zeros(D, dtype=F32, device=dev)
