@@ -248,6 +248,47 @@ def test_finetune_model_schema_and_checkpoint_mapping():
     assert type(feat).__name__ == "VisionTransformer_feat_ext"
 
 
+def test_saved_checkpoint_feeds_the_reference_finetune_loader(tmp_path):
+    """what mofo_amd.utils.save_model writes goes through the reference's fine-tuning loader logic unchanged
+    (run_class_finetuning.py:355-381 restated: pick checkpoint['model'], drop a mismatching head, strip 'backbone.' /
+    'encoder.' prefixes) and lands on every backbone key of the fine-tune model; and the file's key order is the order the
+    reference's own writer produced (tests/golden/ckpt_tiny.npz, written by the reference's utils.save_model)"""
+    import types
+    from collections import OrderedDict
+    from functools import partial
+    from mofo_amd import modeling_pretrain as mp, utils
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    model = mp.PretrainVisionTransformer(img_size=32, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2, decoder_embed_dim=64,
+                                         decoder_depth=1, decoder_num_heads=1, decoder_num_classes=1536, qkv_bias=True,
+                                         norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    opt = types.SimpleNamespace(state_dict=lambda: {"state": {}, "param_groups": []})     # the optimizer entry is exercised on the GPU
+    args = types.SimpleNamespace(output_dir=str(tmp_path))
+    utils.save_model(args, 3, model, model, opt, utils.NativeScalerWithGradNormCount())
+    checkpoint = torch.load(str(tmp_path / "checkpoint-3.pth"), map_location="cpu", weights_only=False)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ckpt_tiny.npz"))
+    assert sorted(checkpoint) == [str(k) for k in g["top_keys"]]
+    assert list(checkpoint["model"]) == [str(k) for k in g["model_keys"]]
+    # --- the reference loader's steps
+    checkpoint_model = None
+    for model_key in "model|module".split("|"):
+        if model_key in checkpoint:
+            checkpoint_model = checkpoint[model_key]
+            break
+    new_dict = OrderedDict()
+    for key in list(checkpoint_model.keys()):
+        if key.startswith("backbone."):
+            new_dict[key[9:]] = checkpoint_model[key]
+        elif key.startswith("encoder."):
+            new_dict[key[8:]] = checkpoint_model[key]
+        else:
+            new_dict[key] = checkpoint_model[key]
+    want = O.finetune_param_shapes(cfg, 10)
+    backbone = [k for k in want if not k.startswith(("head.", "fc_norm."))]
+    assert all(k in new_dict and tuple(new_dict[k].shape) == want[k] for k in backbone)
+    assert torch.equal(new_dict["blocks.1.mlp.fc2.weight"], model.state_dict()["encoder.blocks.1.mlp.fc2.weight"])
+
+
 def test_launcher_flags_and_synthetic_dataset_contract():
     """mofo_amd.run_mae_pretraining: the reference's flag names / defaults for what the path reads (run_mae_pretraining.py:22-131)
     and a dataset whose items have VideoMAE.__getitem__'s layout (kinetics.py:492-495), normalised exactly like the

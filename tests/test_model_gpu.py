@@ -464,6 +464,87 @@ def test_bb_engine_and_checkpoint_roundtrip(dev, tmp_path):
     assert float(l1) == float(l2)
 
 
+def test_checkpoint_interchange_with_reference_writer(dev, tmp_path):
+    """tests/golden/ckpt_tiny.npz: the tiny config trained for two steps by the reference's optimizer + scaler and then
+    WRITTEN by the reference's own utils.save_model (utils.py:411-433; structure kept exactly, tensors as norms + first
+    values).  (1) the same two steps here, saved by mofo_amd.utils.save_model, give a file of the same structure -- top-level
+    keys, model keys / shapes / dtypes, the optimizer's index -> tensor mapping, state keys, param_groups -- and the same
+    tensors (norms, leading values); (2) a file laid out as the reference's (its extra torch.optim.AdamW group keys, `step`
+    as a tensor, empty scaler dict) resumes through auto_load_model and reproduces the reference's THIRD step."""
+    import json
+    import types
+    from mofo_amd import optim_factory, utils
+    from oracle import pretrain_oracle as O
+    g = np.load(os.path.join(G, "ckpt_tiny.npz"))
+    cfg = O.TINY
+
+    class A(_Args):
+        lr = float(g["lr"])
+    model, P = _build(cfg, "xavier", dev)
+    x = O.keyed_clips(2, cfg).to(dev)
+    mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool().to(dev)
+    opt = optim_factory.create_optimizer(A, model)
+    scaler = utils.NativeScalerWithGradNormCount()
+    losses, norms = [], []
+    for _ in range(2):
+        loss = model.forward_loss(x, mask)
+        losses.append(float(loss))
+        opt.zero_grad()
+        norms.append(float(scaler(loss, opt, clip_grad=None)))
+    np.testing.assert_allclose(losses, g["losses12"], rtol=1e-3)
+    np.testing.assert_allclose(norms, g["norms12"], rtol=2e-2)
+    args = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="", start_epoch=0)
+    utils.save_model(args, int(g["epoch"]), model, model, opt, scaler)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint-%d.pth" % int(g["epoch"])), weights_only=False)
+    # ---- (1) structure and contents against the reference-written file
+    assert sorted(ck) == [str(k) for k in g["top_keys"]] and ck["epoch"] == int(g["epoch"])
+    ref_keys = [str(k) for k in g["model_keys"]]
+    assert list(ck["model"]) == ref_keys                                   # same keys in the same (state_dict) order
+    for i, k in enumerate(ref_keys):
+        t = ck["model"][k]
+        assert list(t.shape) == json.loads(str(g["model_shapes"][i])) and str(t.dtype) == str(g["model_dtypes"][i]), k
+        assert float(t.double().norm()) == pytest.approx(g["model_stats"][i, 0], rel=2e-3, abs=1e-6), k
+        # leading values: AdamW's first updates are ~ lr * sign(g), so an element whose tiny gradient changes sign under bf16
+        # noise may sit up to 2 steps x 2 lr away; the per-tensor norm above is the tight check
+        np.testing.assert_allclose(t.double().reshape(-1)[:8].numpy(), g["model_head"][i][: min(8, t.numel())], rtol=2e-2,
+                                   atol=4.2 * float(g["lr"]), err_msg=k)
+    osd = ck["optimizer"]
+    assert sorted(osd["state"]) == g["opt_indices"].tolist()
+    ref_groups = json.loads(str(g["param_groups_json"]))
+    assert [gr["params"] for gr in osd["param_groups"]] == [gr["params"] for gr in ref_groups]   # index -> parameter mapping
+    for mine, ref in zip(osd["param_groups"], ref_groups):
+        for key in ("lr", "weight_decay", "eps", "lr_scale"):
+            assert mine[key] == pytest.approx(ref[key]), key
+        assert tuple(mine["betas"]) == tuple(ref["betas"])
+    total_m = float(np.sqrt((g["opt_stats"][:, 0] ** 2).sum()))
+    for row, i in enumerate(g["opt_indices"].tolist()):
+        st = osd["state"][i]
+        assert sorted(st) == [str(k) for k in g["opt_state_keys"]]
+        assert list(st["exp_avg"].shape) == json.loads(str(g["opt_shapes"][row])) and float(st["step"]) == g["opt_stats"][row, 4]
+        if g["opt_stats"][row, 0] > 1e-3 * total_m:                        # bf16 gradient noise on the tiniest tensors aside
+            assert float(st["exp_avg"].double().norm()) == pytest.approx(g["opt_stats"][row, 0], rel=5e-2), i
+            assert float(st["exp_avg_sq"].double().norm()) == pytest.approx(g["opt_stats"][row, 2], rel=1e-1), i
+    # ---- (2) a file in the reference's exact layout resumes here and continues the reference's trajectory
+    ref_like = {"model": ck["model"], "epoch": int(g["epoch"]), "scaler": {}, "args": types.SimpleNamespace(),
+                "optimizer": {"state": {i: {"step": torch.tensor(float(s["step"])), "exp_avg": s["exp_avg"], "exp_avg_sq": s["exp_avg_sq"]}
+                                        for i, s in osd["state"].items()},
+                              "param_groups": [{**ref, "lr": mine["lr"]} for mine, ref in zip(osd["param_groups"], ref_groups)]}}
+    d2 = tmp_path / "ref_layout"
+    d2.mkdir()
+    torch.save(ref_like, str(d2 / "checkpoint-1.pth"))
+    model2, _ = _build(cfg, "small", dev)                                  # different weights: everything must come from the file
+    opt2 = optim_factory.create_optimizer(A, model2)
+    args2 = types.SimpleNamespace(output_dir=str(d2), auto_resume=True, resume="", start_epoch=0)
+    utils.auto_load_model(args2, model2, model2, opt2, utils.NativeScalerWithGradNormCount())
+    assert args2.start_epoch == 2 and opt2._step == 2
+    loss3 = model2.forward_loss(x, mask)
+    opt2.zero_grad()
+    norm3 = float(utils.NativeScalerWithGradNormCount()(loss3, opt2, clip_grad=None))
+    assert float(loss3) == pytest.approx(float(g["loss3"]), rel=1e-3)
+    assert norm3 == pytest.approx(float(g["norm3"]), rel=2e-2)
+    model2.check_status()
+
+
 def test_gradient_sync_on_one_rank_rccl(dev):
     """exercise the data-parallel plumbing on ONE GPU: RCCL ('nccl') group of size 1, gradient ranges all-reduced
     asynchronously from inside the (replayed) backward launch list, joined before the optimizer.  Results must equal

@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--only-bb-engine", action="store_true", help="only engine_vitb_bb.npz: one step of the reference's own train_one_epoch_BB")
     ap.add_argument("--only-l32", action="store_true", help="only vitl32.npz: ViT-L widths at 32 frames (BASELINE config 4 shapes) through the reference classes")
     ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
+    ap.add_argument("--only-ckpt", action="store_true", help="only ckpt_tiny.npz: a checkpoint WRITTEN by the reference's utils.save_model after two steps")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
@@ -143,6 +144,9 @@ def main():
         return
     if args.only_clip:
         make_clip(args, ref_mp, ref_of, ref_utils, O)
+        return
+    if args.only_ckpt:
+        make_ckpt(args, ref_mp, ref_of, ref_utils, O)
         return
     if args.only_l32:
         make_l32(args, ref_mp, ref_mf, O)
@@ -504,6 +508,81 @@ def make_clip(args, ref_mp, ref_of, ref_utils, O):
     np.savez_compressed(os.path.join(args.out, "tiny_clip.npz"), clip_grad=np.array(0.1), losses=np.array(losses), norms=np.array(norms),
                         names=np.array(names), param_stats_after3=pstat, param_head_after3=phead)
     print("tiny_clip: losses", losses, "norms (before clipping)", norms)
+
+
+def make_ckpt(args, ref_mp, ref_of, ref_utils, O):
+    """ckpt_tiny.npz: the tiny config trained for two steps with the reference's optimizer + scaler, then WRITTEN by the
+    reference's own utils.save_model (utils.py:411-433) and read back with torch.load; the file's tensors are stored as plain
+    arrays (model/<key>, opt/<index>/{exp_avg,exp_avg_sq,step}, the param_groups as JSON) next to the loss and gradient norm
+    of the reference's THIRD step, which a resumed run must reproduce."""
+    import contextlib
+    import io
+    import json
+    import tempfile
+    from functools import partial as _partial
+
+    class OptArgs:
+        opt, lr, weight_decay, opt_eps, opt_betas, momentum = "adamw", 1.5e-3, 0.05, 1e-8, (0.9, 0.95), 0.9
+
+    cfg = O.TINY
+    P = O.keyed_params(cfg, "xavier")
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = ref_mp.PretrainVisionTransformer(
+            img_size=cfg.img_size, patch_size=cfg.patch_size, encoder_embed_dim=cfg.enc_dim, encoder_depth=cfg.enc_depth,
+            encoder_num_heads=cfg.enc_heads, encoder_num_classes=0, decoder_num_classes=cfg.patch_dim, decoder_embed_dim=cfg.dec_dim,
+            decoder_depth=cfg.dec_depth, decoder_num_heads=cfg.dec_heads, mlp_ratio=cfg.mlp_ratio, qkv_bias=True,
+            norm_layer=_partial(torch.nn.LayerNorm, eps=1e-6))
+    model.load_state_dict(P, strict=True)
+    videos = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(np.load(os.path.join(args.out, "masks.npz"))["tube_tiny_s10"]).bool()
+    labels = O.build_targets(videos, mask, cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        opt = ref_of.create_optimizer(OptArgs, model)
+    scaler = ref_utils.NativeScalerWithGradNormCount()
+
+    def step():
+        loss = torch.nn.MSELoss()(model(videos, mask), labels)
+        opt.zero_grad()
+        norm = scaler(loss, opt, clip_grad=None, parameters=model.parameters())
+        return loss.item(), float(norm)
+
+    first = [step() for _ in range(2)]
+    with tempfile.TemporaryDirectory() as td:
+        a = argparse.Namespace(output_dir=td)
+        ref_utils.save_model(a, 1, model, model, opt, scaler)                       # the reference's own writer
+        ck = torch.load(os.path.join(td, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
+    third = step()
+    # The file itself would be 8 MB (parameters + two moments); the fixture keeps its STRUCTURE exactly (key lists in file
+    # order, shapes, dtypes, the optimizer's index -> tensor mapping, param_groups) and every tensor's L2 norm + first values.
+    def stat(t):
+        t = t.detach().double().reshape(-1)
+        return np.array([float(t.norm()), float(t.sum())]), t[:8].numpy()
+
+    out = {"top_keys": np.array(sorted(ck.keys())), "epoch": np.array(ck["epoch"]), "scaler_keys": np.array(sorted(ck["scaler"].keys()), dtype="U16"),
+           "model_keys": np.array(list(ck["model"].keys())), "losses12": np.array([f[0] for f in first]), "norms12": np.array([f[1] for f in first]),
+           "loss3": np.array(third[0]), "norm3": np.array(third[1]), "lr": np.array(OptArgs.lr),
+           "model_dtypes": np.array([str(v.dtype) for v in ck["model"].values()])}
+    mstat, mhead, mshape = [], [], []
+    for k, v in ck["model"].items():
+        a, b = stat(v)
+        mstat.append(a), mhead.append(np.pad(b, (0, 8 - len(b)))), mshape.append(json.dumps(list(v.shape)))
+    out["model_stats"], out["model_head"], out["model_shapes"] = np.array(mstat), np.array(mhead), np.array(mshape)
+    so = ck["optimizer"]
+    groups = []
+    for g in so["param_groups"]:
+        groups.append({k: (list(v) if isinstance(v, (tuple, list)) else v) for k, v in g.items()})
+    out["param_groups_json"] = np.array(json.dumps(groups))
+    out["opt_state_keys"] = np.array(sorted(next(iter(so["state"].values())).keys()))
+    out["opt_indices"] = np.array(sorted(so["state"].keys()))
+    ostat, oshape = [], []
+    for i in sorted(so["state"].keys()):
+        st = so["state"][i]
+        ostat.append(np.concatenate([stat(st["exp_avg"])[0], stat(st["exp_avg_sq"])[0], [float(st["step"])]]))
+        oshape.append(json.dumps(list(st["exp_avg"].shape)))
+    out["opt_stats"], out["opt_shapes"] = np.array(ostat), np.array(oshape)
+    out["opt_step_is_tensor"] = np.array(isinstance(next(iter(so["state"].values()))["step"], torch.Tensor))
+    np.savez_compressed(os.path.join(args.out, "ckpt_tiny.npz"), **out)
+    print("ckpt_tiny: top keys", sorted(ck.keys()), "epoch", ck["epoch"], "losses", first, "third step", third, "groups", [len(g["params"]) for g in so["param_groups"]])
 
 
 def make_next(args, ref_mg, ref_mf, O):
