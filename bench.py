@@ -84,9 +84,13 @@ def main():
     ap.add_argument("--input", choices=["f32", "uint8"], default="f32",
                     help="f32: the model's input contract (normalised clips in HBM); uint8: the loader's frame stack [B,H,W,T*3], "
                          "normalised inside the gather / target kernels (side measurement)")
+    ap.add_argument("--fp8", action="store_true", help="side measurement (BASELINE configs[4]): the LayerNorm-fed forward Linears (qkv, fc1) on OCP "
+                                                       "e4m3 operands with the block-scaled MFMA; everything else bf16")
     ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
                     help="vitb16: the headline workload (BASELINE configs[1]/[2]); vitl32: ViT-L, 32 frames (configs[4] in bf16; side measurement)")
     args = ap.parse_args()
+    if args.fp8:
+        os.environ["MOFO_FP8"] = "1"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -227,7 +231,8 @@ def main():
 
     out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step" if args.model == "vitb16" else "clips/sec (32x3x224x224, mask 90%) ViT-L pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "bf16" if not args.fp8 else "fp8 e4m3 (forward qkv / fc1 GEMMs) + bf16", "data": "synthetic",
            "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
                                   "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),

@@ -29,7 +29,11 @@ const char* mofo_last_error(void);
  *      modeling_finetune.py:238-247 as a dot product per tubelet; plus their autograd dgrad / wgrad. ---- */
 enum { MOFO_GEMM_NT = 0, /* C[m,n] = sum_k A[m,k] B[n,k]  forward  */
        MOFO_GEMM_NN = 1, /* C[m,n] = sum_k A[m,k] B[k,n]  dgrad    */
-       MOFO_GEMM_TN = 2  /* C[m,n] = sum_k A[k,m] B[k,n]  wgrad    */ };
+       MOFO_GEMM_TN = 2, /* C[m,n] = sum_k A[k,m] B[k,n]  wgrad    */
+       MOFO_GEMM_NT_FP8 = 3 /* NT on e4m3 operands (see below)       */ };
+/* MOFO_GEMM_NT_FP8 (op 3): the NT form on OCP e4m3 operands (1 byte per element, lda / ldb in bytes, K a multiple of 128),
+ * block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: 2x the bf16 MFMA rate), f32 accumulate; the
+ * per-tensor de-quantisation factors are read on the device.  Epilogues BF16 and BIAS_GELU.  BASELINE configs[4]'s fp8 forward. */
 enum { MOFO_EPI_BF16 = 0,       /* C(bf16) = acc (+bias[n])                                            */
        MOFO_EPI_BIAS_GELU = 1,  /* h = acc+bias; C(bf16)=h; C2(bf16)=gelu_erf(h)   (fc1 + nn.GELU)      */
        MOFO_EPI_RESID_F32 = 2,  /* C(f32) = resid(f32) + acc (+bias)   (proj / fc2 + residual add)      */
@@ -55,6 +59,8 @@ typedef struct mofo_gemm_args {
     int accumulate;               /* F32 epilogue: add into C instead of overwrite */
     float* colsum;                /* TN + F32 only (wgrad): colsum[m] += sum_k A[k,m] = the bias gradient, fused; or NULL */
     int colsum_skip_lo, colsum_skip_hi; /* rows m in [lo,hi) of colsum are left untouched (k third of the fused qkv bias) */
+    const float* a_scale_inv;     /* NT_FP8: device scalars; C = epilogue(a_scale_inv[0] * b_scale_inv[0] * sum_k A8 B8) */
+    const float* b_scale_inv;
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
 /* up to 4 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of a transformer block) */
@@ -70,6 +76,11 @@ int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* str
 int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
+/* the same, and the normalised rows ALSO as OCP e4m3 (y_e4m3 [M, ldy8] = sat(y * qscale[0])): the A operand of the fp8 forward
+ * GEMMs (MOFO_GEMM_NT_FP8).  amax_out collects max|y| over a sample of the rows (atomic max) for the caller's next scale. */
+int mofo_layernorm_fwd_q(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
+                         int rows_in, int rows_out, int row_off, void* y_bf16, int ldy, float* mean, float* rstd,
+                         void* y_e4m3, int ldy8, const float* qscale, float* amax_out, void* stream);
 /* dx = dres + LN'(dy).  The incoming residual-stream gradient is dres (f32) OR dres_bf16 (bf16) OR neither; the result
  * goes to dx (f32) and/or dx_bf16 (at least one).  dw/db accumulate (+=): with partial_ws the per-block partials are stored
  * and summed by a second tiny kernel (one writer per address, deterministic); without it every block adds atomically. */
@@ -113,6 +124,17 @@ int mofo_attention_delta_zero_dq(const void* out, int ldo, const void* dout, int
                                  void* dqkv, int lddqkv, void* stream);
 int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
+
+/* ---- OCP e4m3 quantisation for MOFO_GEMM_NT_FP8 (per-tensor scales; BASELINE configs[4]).
+ * segments: x is a flat bf16 buffer of n = 1024 * chunks elements; chunk_seg[c] names the tensor ("segment", 0..nseg-1) chunk c
+ * belongs to, or -1 (left untouched).  Per segment: amax -> out = sat_e4m3(x * 448 / amax), scale_inv[seg] = amax / 448.
+ * amax_ws: nseg floats of scratch.  (The runtime quantises the whole bf16 weight shadow with it: two launches per step.) */
+int mofo_fp8_quantize_segments(const void* x_bf16, long long n, const short* chunk_seg, int nseg, float* amax_ws,
+                               void* out_e4m3, float* scale_inv, void* stream);
+/* out = sat_e4m3(x * scale[0]) for a plain bf16 tensor; amax_out (or NULL) collects max|x| by atomic max */
+int mofo_fp8_quantize_bf16(const void* x_bf16, long long n, const float* scale, void* out_e4m3, float* amax_out, void* stream);
+/* delayed scaling: scales[2i] = 448 / (amax[i] * margin), scales[2i+1] = its inverse; amax[i] is cleared.  amax[i] == 0 keeps the old pair */
+int mofo_fp8_update_scales(float* amax, float* scales, int n, float margin, void* stream);
 
 /* ---- masks -> index lists: replaces the boolean gathers x[~mask] / pos[mask] of modeling_pretrain.py:90,261-262
  * and engine_for_pretraining.py:63 (which cost a device->host sync in the reference).  mask: uint8 [B,N], 1 = masked.

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmofo_hip.so")
 
 # enums (mirror include/mofo_hip.h)
-GEMM_NT, GEMM_NN, GEMM_TN = 0, 1, 2
+GEMM_NT, GEMM_NN, GEMM_TN, GEMM_NT_FP8 = 0, 1, 2, 3
 EPI_BF16, EPI_BIAS_GELU, EPI_RESID_F32, EPI_POS_F32, EPI_DGELU_BF16, EPI_F32, EPI_RESID_BF16, EPI_POS_BF16 = 0, 1, 2, 3, 4, 5, 6, 7
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -23,7 +23,8 @@ class GemmArgs(C.Structure):
                 ("A", _vp), ("lda", _i), ("B", _vp), ("ldb", _i), ("C", _vp), ("ldc", _i), ("C2", _vp), ("ldc2", _i),
                 ("bias", _vp), ("resid", _vp), ("ldr", _i), ("aux", _vp), ("ldaux", _i),
                 ("pos", _vp), ("ldpos", _i), ("row_idx", _vp), ("rows_in", _i), ("rows_out", _i), ("row_off", _i),
-                ("splits", _i), ("accumulate", _i), ("colsum", _vp), ("colsum_skip_lo", _i), ("colsum_skip_hi", _i)]
+                ("splits", _i), ("accumulate", _i), ("colsum", _vp), ("colsum_skip_lo", _i), ("colsum_skip_hi", _i),
+                ("a_scale_inv", _vp), ("b_scale_inv", _vp)]
 
 
 _SIGS = {
@@ -33,6 +34,10 @@ _SIGS = {
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "mofo_layernorm_fwd_q": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
+    "mofo_fp8_quantize_segments": (_i, [_vp, _ll, _vp, _i, _vp, _vp, _vp, _vp]),
+    "mofo_fp8_quantize_bf16": (_i, [_vp, _ll, _vp, _vp, _vp, _vp]),
+    "mofo_fp8_update_scales": (_i, [_vp, _vp, _i, _f, _vp]),
     "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "mofo_layernorm_bwd_blocks": (_i, [_i]),
     "mofo_layernorm_bwd_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "attention.hip", "layernorm.hip", "tokens.hip", "loss.hip", "optim.hip", "capi.cpp"]
+SOURCES = ["gemm.hip", "attention.hip", "layernorm.hip", "tokens.hip", "loss.hip", "optim.hip", "quant.hip", "capi.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
          # keep MFMA accumulators in arch VGPRs: with the default AGPR form hipcc (ROCm 7.2) copied every accumulator in
          # and out of the AGPR file each loop iteration (100 v_accvgpr_* per 16 MFMAs in the GEMM main loop)

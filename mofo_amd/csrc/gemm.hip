@@ -46,7 +46,7 @@ struct GemmP {
     float* colsum;            // TN only: colsum[m] += sum_k A[k,m]  (bias gradient riding on the wgrad GEMM), or null
     int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
     int rotate;               // persistent form: rotated reduction order per tile (see gemm_persistent_kernel)
-    int nt_a;                 // A operand staged with non-temporal loads (persistent form)
+    const float* a_scale_inv; const float* b_scale_inv;   // NT_FP8: per-tensor de-quantisation factors (device scalars)
     int rotate_tile;          // the same in the one-tile-per-block kernel (MOFO_GEMM_ROTATE_TILE=0 turns it off): small-grid
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
 };
@@ -157,10 +157,10 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned char* lds_tile, int s
 // 5k / 16k / 25k clk for the bf16 / dGELU / residual epilogues beside a 13k-clk K=384 main loop.  Hence: (1) tiles that
 // lie wholly inside C take a branch-free, fully unrolled path; (2) residual / pre-activation rows are loaded in chunks of
 // up to 32 VGPRs, the first chunk BEFORE the accumulators are staged, the next one before the current one is consumed.
-template <int EPI, int MI, int PASSES>
+template <int EPI, int MI, int PASSES, bool SCALED = false>
 __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], float* ep, int mb, int nb, bool full_tile, int lane,
-                                         bool stamp = true) {   // mb, nb: first row / column of the wave's tile; stamp: trace builds only
-    (void)stamp;
+                                         bool stamp = true, float alpha = 1.0f) {   // mb, nb: first row / column of the wave's tile; stamp: trace builds only
+    (void)stamp;                                                                     // alpha (SCALED): fp8 de-quantisation factor
     constexpr int WROWS = 16 * MI;              // rows of the wave tile
     constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16);
@@ -174,7 +174,8 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c4 = 4 * j + (lane >> 4);
-                *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
+                if constexpr (SCALED) *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j] * alpha;
+                else *(f32x4*)(ep + r * 64 + ((c4 ^ (r & 15)) << 2)) = acc[i][j];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -539,8 +540,7 @@ __global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(G
     auto stage = [&](int m0, int n0, int t) {
         int kc = t + m0 / BMT + n0 / BN;
         kc = p.rotate ? kc % nk : t;
-        if (p.nt_a) stage_tile_srd<LA, MI, 2>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
-        else stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
+        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, kc * BK, smem, wave_u);
         stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, kc * BK, smem + A_BYTES, wave_u);
     };
     const unsigned char* ta = smem;
@@ -712,6 +712,92 @@ __global__ __launch_bounds__(512, 2) void gemm_ksplit_kernel(GemmP p, int total)
                         (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false);
 }
 
+// NT on OCP e4m3 operands (BASELINE configs[4]: "fp8 MFMA attention/MLP"; here the forward Linears whose A operand is a
+// LayerNorm output: qkv and fc1).  One byte per element, so a 128-row x 128-BYTE operand tile has exactly the bf16 ROW
+// image's geometry (128-B rows, 16-B chunk c of row r at c ^ (r & 7)) with twice the reduction depth; the MFMA is the
+// block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit (e8m0 = 127) block scales -- 2x the bf16 rate -- and lane l feeds
+// row l & 15, reduction bytes 32 (l >> 4) .. + 31 (two ds_read_b128).  Two LDS stages, LDS-DMA staging, the shared epilogue
+// with the per-tensor de-quantisation factor a_scale_inv * b_scale_inv applied to the f32 accumulators.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+template <int NI>
+__device__ __forceinline__ void stage_tile_bytes(__amdgpu_buffer_rsrc_t rsrc, int voff, int ld, int d0, int k0, unsigned char* lds_tile, int wave_u) {
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int i = wave_u * NI + j;
+        const unsigned soff = (unsigned)(d0 + 8 * i) * (unsigned)ld + (unsigned)k0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, voff, (int)soff, 0, 0);
+    }
+}
+__device__ __forceinline__ i32x8 read_frag_fp8(const unsigned char* lds_tile, int sub0, int lane) {
+    const int row = sub0 + (lane & 15);
+    const int kc = 2 * (lane >> 4);
+    const u32x4 lo = *(const u32x4*)(lds_tile + row * 128 + ((kc ^ (row & 7)) << 4));
+    const u32x4 hi = *(const u32x4*)(lds_tile + row * 128 + (((kc + 1) ^ (row & 7)) << 4));
+    i32x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+template <int EPI, int MI>
+__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
+    constexpr int BMT = 32 * MI;
+    constexpr int A_BYTES = BMT * 128;
+    constexpr int STG = A_BYTES + 128 * 128;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    int m0, n0;
+    {
+        const int w = blockIdx.x;
+        const int q = total >> 3, r = total & 7, xcd = w & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+        m0 = (wg / tiles_n) * BMT;
+        n0 = (wg % tiles_n) * BN;
+    }
+    const int nk = p.K / 128;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)p.M - 1) * p.lda + p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)p.N - 1) * p.ldb + p.K), 0x00020000);
+    const int va = (lane >> 3) * p.lda + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    const int vb = (lane >> 3) * p.ldb + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    auto stage = [&](int t, int buf) {
+        unsigned char* ta = smem + buf * STG;
+        stage_tile_bytes<MI>(ra, va, p.lda, m0, t * 128, ta, wave_u);
+        stage_tile_bytes<4>(rb, vb, p.ldb, n0, t * 128, ta + A_BYTES, wave_u);
+    };
+    f32x4 acc[MI][4];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float alpha = p.a_scale_inv[0] * p.b_scale_inv[0];
+    stage(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int t = 0; t < nk; ++t) {
+        if (t + 1 < nk) stage(t + 1, cur ^ 1);
+        const unsigned char* ta = smem + cur * STG;
+        const unsigned char* tb = ta + A_BYTES;
+        i32x8 af[MI], bfr[4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[i] = read_frag_fp8(ta, wm * (16 * MI) + 16 * i, lane);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bfr[i] = read_frag_fp8(tb, wn * 64 + 16 * i, lane);
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)   // (B, A) operand order as in the bf16 kernels: a lane ends up with 4 consecutive n of one m
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+    static_assert(4 * (16 * MI) * 64 * 4 <= 2 * STG, "epilogue staging must fit the main-loop LDS");
+    epilogue<EPI, MI, 1, true>(p, acc, (float*)smem + wave * ((16 * MI) * 64), m0 + wm * (16 * MI), n0 + wn * 64,
+                               (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false, alpha);
+}
+
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
 // (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
 //   wgrad (TN)            VAR 1: 2.30 ms/step vs 2.69 for VAR 0 (3 blocks per CU; fits 168 VGPRs since the SRD staging)
@@ -781,6 +867,12 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
     // alignment / divisibility the kernels are built for
     if (a->N % 8 || a->lda % 8 || a->ldb % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: N, lda, ldb must be multiples of 8");
     if (op == MOFO_GEMM_NT && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT: K=%d must be a multiple of 64", a->K);
+    if (op == MOFO_GEMM_NT_FP8) {
+        if (a->K % 128 || a->lda % 16 || a->ldb % 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: K must be a multiple of 128, lda / ldb of 16");
+        if (!a->a_scale_inv || !a->b_scale_inv) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm NT_FP8: needs the device scalars a_scale_inv, b_scale_inv");
+        if (epi != MOFO_EPI_BF16 && epi != MOFO_EPI_BIAS_GELU) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: epilogues BF16 and BIAS_GELU only");
+        if ((a->splits > 1) || a->accumulate) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: no split-K / accumulate");
+    }
     if (op == MOFO_GEMM_NN && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NN: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_TN && a->M % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm TN: M=%d must be a multiple of 8", a->M);
     const bool out_bf16 = (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_DGELU_BF16 || epi == MOFO_EPI_RESID_BF16 ||
@@ -797,8 +889,10 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
         // the operands are addressed through 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets):
         // an operand image of 2 GiB or more is refused instead of wrapping (split the rows / the reduction on the caller's side)
         const long long ra = op == MOFO_GEMM_TN ? a->K : a->M, ca = op == MOFO_GEMM_TN ? a->M : a->K;
-        const long long rb = op == MOFO_GEMM_NT ? a->N : a->K, cb = op == MOFO_GEMM_NT ? a->K : a->N;
-        const long long ext_a = ((ra - 1) * a->lda + ca) * 2, ext_b = ((rb - 1) * a->ldb + cb) * 2;
+        const bool ntlike = op == MOFO_GEMM_NT || op == MOFO_GEMM_NT_FP8;
+        const long long rb = ntlike ? a->N : a->K, cb = ntlike ? a->K : a->N;
+        const long long esz = op == MOFO_GEMM_NT_FP8 ? 1 : 2;
+        const long long ext_a = ((ra - 1) * a->lda + ca) * esz, ext_b = ((rb - 1) * a->ldb + cb) * esz;
         // + one ragged tile of slack: offsets of rows past the end are formed before the range check drops them
         const long long slack = 256LL * (a->lda > a->ldb ? a->lda : a->ldb) * 2;
         if (ext_a + slack >= (1LL << 31) || ext_b + slack >= (1LL << 31))
@@ -815,6 +909,8 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
     splits = ceil_div(a->K, kps);
     p.k_per_split = kps;
     p.atomic = (splits > 1 || a->accumulate) ? 1 : 0;
+    p.a_scale_inv = a->a_scale_inv;
+    p.b_scale_inv = a->b_scale_inv;
     p.colsum = a->colsum;
     p.colsum_skip_lo = a->colsum_skip_lo;
     p.colsum_skip_hi = a->colsum_skip_hi;
@@ -835,12 +931,6 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
             rt = e ? atoi(e) : 1;
         }
         p.rotate_tile = rt;
-        static int nta = -2;
-        if (nta == -2) {
-            const char* e = getenv("MOFO_GEMM_NT_A");
-            nta = e ? atoi(e) : 0;
-        }
-        p.nt_a = nta;
     }
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
     blocks = ceil_div(a->M, bm) * ceil_div(a->N, BN) * splits;
@@ -870,6 +960,18 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
             case MOFO_EPI_F32: GO(OPL_COL, OPL_COL, MOFO_EPI_F32);
             case MOFO_EPI_BF16: GO(OPL_COL, OPL_COL, MOFO_EPI_BF16);
         }
+    } else if (op == MOFO_GEMM_NT_FP8 && g.count == 1) {
+        const GemmP& p = g.p[0];
+        const int total = g.start[1];
+        if (epi == MOFO_EPI_BF16) {
+            if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 2>), dim3(total), dim3(256), 0, s, p, total);
+            else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 4>), dim3(total), dim3(256), 0, s, p, total);
+        } else {
+            if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 2>), dim3(total), dim3(256), 0, s, p, total);
+            else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 4>), dim3(total), dim3(256), 0, s, p, total);
+        }
+        MOFO_CHECK_LAUNCH("mofo_gemm(fp8)");
+        return MOFO_OK;
     }
 #undef GO
     MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: op %d with epilogue %d is not built", op, epi);
@@ -898,7 +1000,7 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
             mi8 = e8 ? atoi(e8) : -1;
         }
         if (mi != 2 && mi8 != 0 && count == 1 && a[0].splits <= 1 && !a[0].accumulate && a[0].epilogue != MOFO_EPI_POS_F32 &&
-            a[0].epilogue != MOFO_EPI_POS_BF16) {
+            a[0].epilogue != MOFO_EPI_POS_BF16 && a[0].op != MOFO_GEMM_NT_FP8) {
             const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, BN);
             const double eff4 = (double)t128 / (double)(ceil_div((int)t128, 768) * 768);
             const double eff8 = (double)t256 / (double)(ceil_div((int)t256, 512) * 512);

@@ -13,11 +13,16 @@ __device__ __forceinline__ size_t map_row(int r, int rows_in, int rows_out, int 
 }
 
 // XB: the residual stream is bf16 (the decoder, runtime.py) instead of f32: 8-byte loads of four elements per lane.
-template <int NIT, bool XB>
+// Q8: the normalised row also goes out as OCP e4m3 (the A operand of the fp8 forward GEMMs, gemm.hip NT_FP8), multiplied by
+// qscale[0]; every 64th block reports its rows' |y| maximum to amax_out (delayed scaling: enough of a sample to set the
+// NEXT step's scale -- one atomic per block on a single address would cost more than the LayerNorm itself).
+template <int NIT, bool XB, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv_, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps, int M, int D, int rows_in,
                                                       int rows_out, int row_off, bf16_t* __restrict__ y, int ldy,
-                                                      float* __restrict__ mean, float* __restrict__ rstd) {
+                                                      float* __restrict__ mean, float* __restrict__ rstd,
+                                                      uint8_t* __restrict__ y8 = nullptr, int ldy8 = 0,
+                                                      const float* __restrict__ qscale = nullptr, float* __restrict__ amax_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = blockIdx.x * 4 + wave;
     if (r >= M) return;
@@ -57,6 +62,8 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
         rstd[r] = rs;
     }
     bf16_t* yr = y + (size_t)r * ldy;
+    float qs = 1.f, am = 0.f;
+    if constexpr (Q8) qs = qscale[0];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int c = (it * 64 + lane) * 4;
@@ -68,6 +75,20 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
             for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - mu) * rs * wv[e] + bv[e];
             u32x2 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
             *(u32x2*)(yr + c) = pk;
+            if constexpr (Q8) {
+                // quantise what the bf16 consumers see (the rounded values), so both forms of the activation agree
+                const float q0 = bf16lo_to_f32(pk[0]), q1 = bf16hi_to_f32(pk[0]), q2 = bf16lo_to_f32(pk[1]), q3 = bf16hi_to_f32(pk[1]);
+                am = fmaxf(am, fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))));
+                int rq = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q0 * qs, -448.f, 448.f), __builtin_amdgcn_fmed3f(q1 * qs, -448.f, 448.f), 0, false);
+                rq = __builtin_amdgcn_cvt_pk_fp8_f32(__builtin_amdgcn_fmed3f(q2 * qs, -448.f, 448.f), __builtin_amdgcn_fmed3f(q3 * qs, -448.f, 448.f), rq, true);
+                *(uint32_t*)(y8 + (size_t)r * ldy8 + c) = (uint32_t)rq;
+            }
+        }
+    }
+    if constexpr (Q8) {
+        if ((blockIdx.x & 63) == 0) {
+            am = wave_max(am);
+            if (lane == 0) atomicMax((unsigned*)amax_out, __float_as_uint(am));
         }
     }
 }
@@ -318,6 +339,24 @@ extern "C" int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const f
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO
     MOFO_CHECK_LAUNCH("mofo_layernorm_fwd");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_layernorm_fwd_q(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
+                                    int rows_in, int rows_out, int row_off, void* y, int ldy, float* mean, float* rstd,
+                                    void* y_e4m3, int ldy8, const float* qscale, float* amax_out, void* stream) {
+    if (!x || !w || !b || !y || !mean || !rstd || !y_e4m3 || !qscale || !amax_out) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_fwd_q: null pointer");
+    int rc = ln_check("mofo_layernorm_fwd_q", M, D, rows_in, rows_out);
+    if (rc) return rc;
+    if (ldx % 4 || ldy % 4 || ldy8 % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_fwd_q: leading dims must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    const int nit = ceil_div(D, 256);
+    dim3 grid(ceil_div(M, 4)), block(256);
+#define GO(N_) do { if (x_is_bf16) hipLaunchKernelGGL((ln_fwd_kernel<N_, true, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)y_e4m3, ldy8, qscale, amax_out); \
+                    else hipLaunchKernelGGL((ln_fwd_kernel<N_, false, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)y_e4m3, ldy8, qscale, amax_out); } while (0)
+    switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
+#undef GO
+    MOFO_CHECK_LAUNCH("mofo_layernorm_fwd_q");
     return MOFO_OK;
 }
 

@@ -9,9 +9,10 @@ import torch
 
 from . import _lib
 from ._lib import (EPI_BF16, EPI_BIAS_GELU, EPI_DGELU_BF16, EPI_F32, EPI_POS_BF16, EPI_POS_F32, EPI_RESID_BF16, EPI_RESID_F32,
-                   GEMM_NN, GEMM_NT, GEMM_TN, GemmArgs)
+                   GEMM_NN, GEMM_NT, GEMM_NT_FP8, GEMM_TN, GemmArgs)
 
 BF16, F32, I32, U8 = torch.bfloat16, torch.float32, torch.int32, torch.uint8
+F8 = torch.float8_e4m3fn     # OCP e4m3 (gfx950's fp8), the storage type of the fp8 forward GEMM operands
 
 
 _STREAM_OVERRIDE = None   # a torch.cuda.Stream while a launch sequence runs part of its work on a side stream
@@ -124,9 +125,12 @@ def gemm_grouped(op, epi, problems):
 
 
 def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
-               row_off=0, splits=1, accumulate=False, colsum=None, colsum_skip=(0, 0)):
-    _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
-    if op == GEMM_NT:
+               row_off=0, splits=1, accumulate=False, colsum=None, colsum_skip=(0, 0), a_scale_inv=None, b_scale_inv=None):
+    if op == GEMM_NT_FP8:
+        _chk(A, F8, "A", 2), _chk(B, F8, "B", 2), _chk(a_scale_inv, F32, "a_scale_inv"), _chk(b_scale_inv, F32, "b_scale_inv")
+    else:
+        _chk(A, BF16, "A", 2), _chk(B, BF16, "B", 2)
+    if op in (GEMM_NT, GEMM_NT_FP8):
         M, K = A.shape
         N, K2 = B.shape
     elif op == GEMM_NN:
@@ -174,10 +178,10 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
                  ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
                  rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0, colsum=_p(colsum),
-                 colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1])
+                 colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1], a_scale_inv=_p(a_scale_inv), b_scale_inv=_p(b_scale_inv))
     # algorithmic HBM bytes of the launch: every operand read once, every output written once (bench.py's roofline block)
     esz = 4.0 if out_dtype == F32 else 2.0
-    nbytes = 2.0 * (M * K + N * K) + esz * M * N
+    nbytes = A.element_size() * (M * K + N * K) + esz * M * N
     if epi == EPI_BIAS_GELU:
         nbytes += 2.0 * M * N
     elif epi == EPI_RESID_F32:
@@ -214,6 +218,50 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
     _run("mofo_layernorm_fwd", ("ln_fwd",), (4.0 if xb else 6.0) * M * D, _p(x), xb, _ld(x), _p(w), _p(b), eps, M, D, rows_in, rows_out, row_off,
          _p(y), _ld(y), _p(mean), _p(rstd))
     return y
+
+
+def layernorm_fwd_q(x, w, b, eps, y, mean, rstd, y8, qscale, amax_out):
+    """layernorm_fwd that also writes the rows as e4m3 (y8 = sat(y * qscale[0])) and reports a sampled max|y| into amax_out"""
+    if x is None or x.dtype not in (F32, BF16):
+        raise TypeError("x must be f32 or bf16")
+    _chk(x, x.dtype, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(y, BF16, "y", 2), _chk(mean, F32, "mean", 1), _chk(rstd, F32, "rstd", 1)
+    _chk(y8, F8, "y8", 2), _chk(qscale, F32, "qscale"), _chk(amax_out, F32, "amax_out")
+    M, D = y.shape
+    if x.shape != (M, D) or y8.shape != (M, D) or w.numel() != D or b.numel() != D or mean.numel() < M or rstd.numel() < M:
+        raise ValueError("layernorm_fwd_q: shape mismatch")
+    xb = 1 if x.dtype == BF16 else 0
+    _run("mofo_layernorm_fwd_q", ("ln_fwd",), (5.0 if xb else 7.0) * M * D, _p(x), xb, _ld(x), _p(w), _p(b), eps, M, D, M, M, 0, _p(y), _ld(y),
+         _p(mean), _p(rstd), _p(y8), _ld(y8), _p(qscale), _p(amax_out))
+    return y8
+
+
+def fp8_quantize_segments(x_bf16, chunk_seg, nseg, amax_ws, out8, scale_inv):
+    """flat bf16 buffer -> flat e4m3 buffer, one scale per segment (chunk_seg: int16 per 1024-element chunk, -1 = skip)"""
+    _chk(x_bf16, BF16, "x", 1), _chk(out8, F8, "out8", 1), _chk(amax_ws, F32, "amax_ws", 1), _chk(scale_inv, F32, "scale_inv", 1)
+    if chunk_seg is None or chunk_seg.dtype != torch.int16 or not chunk_seg.is_cuda:
+        raise TypeError("chunk_seg must be an int16 GPU tensor")
+    n = x_bf16.numel()
+    if out8.numel() != n or chunk_seg.numel() * 1024 != n or amax_ws.numel() < nseg or scale_inv.numel() < nseg:
+        raise ValueError("fp8_quantize_segments: size mismatch")
+    _run("mofo_fp8_quantize_segments", ("fp8_quant_w",), 5.0 * n, _p(x_bf16), n, _p(chunk_seg), int(nseg), _p(amax_ws), _p(out8), _p(scale_inv))
+
+
+def fp8_quantize_bf16(x, scale, out8, amax_out=None):
+    _chk(x, BF16, "x"), _chk(scale, F32, "scale"), _chk(out8, F8, "out8")
+    if not x.is_contiguous() or not out8.is_contiguous() or out8.numel() != x.numel():
+        raise ValueError("fp8_quantize_bf16: contiguous tensors of one size")
+    if amax_out is not None:
+        _chk(amax_out, F32, "amax_out")
+    _run("mofo_fp8_quantize_bf16", ("fp8_quant",), 3.0 * x.numel(), _p(x), x.numel(), _p(scale), _p(out8), _p(amax_out))
+    return out8
+
+
+def fp8_update_scales(amax, scales, margin=1.5):
+    _chk(amax, F32, "amax", 1), _chk(scales, F32, "scales", 2)
+    n = amax.numel()
+    if tuple(scales.shape) != (n, 2) or not scales.is_contiguous():
+        raise ValueError("fp8_update_scales: scales must be [n, 2]")
+    _run("mofo_fp8_update_scales", ("fp8_scales",), 12.0 * n, _p(amax), _p(scales), n, float(margin))
 
 
 def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):

@@ -125,6 +125,7 @@ class FlatStore:
                 p.data = v
         self.attach_grads()
         self._shadow_version = -1
+        self.shadow_epoch = 0      # bumped whenever the bf16 shadow changes (the e4m3 shadow follows it)
         self.fresh = True
         self.numel = sum(p.numel() for _, p in named_params)
 
@@ -188,9 +189,38 @@ class FlatStore:
         if force or v != self._shadow_version:
             ops.cast_bf16(self.params, self.shadow)
             self._shadow_version = v
+            self.shadow_epoch += 1
 
     def mark_shadow_fresh(self):
         self._shadow_version = self._version()
+        self.shadow_epoch += 1
+
+    # ---- OCP e4m3 copy of the GEMM weights named by ``enable_fp8`` (the fp8 forward GEMMs, BASELINE configs[4])
+    def enable_fp8(self, names):
+        """a flat e4m3 shadow beside the bf16 one, one per-tensor scale per matrix in ``names``; refreshed by refresh_shadow8()"""
+        self.fp8_names = list(names)
+        seg = np.full(self.total // CHUNK, -1, dtype=np.int16)
+        for i, n in enumerate(self.fp8_names):
+            o, k = self.offset[n], int(np.prod(self.shape[n]))
+            seg[o // CHUNK: (o + k + CHUNK - 1) // CHUNK] = i
+        self.chunk_seg = torch.from_numpy(seg).to(self.device)
+        self.shadow8 = torch.zeros(self.total, dtype=torch.float8_e4m3fn, device=self.device)
+        self.w_scale_inv = torch.ones(len(self.fp8_names), dtype=F32, device=self.device)
+        self._amax_ws = torch.zeros(len(self.fp8_names), dtype=F32, device=self.device)
+        self._shadow8_epoch = -1
+
+    def b8view(self, name):
+        s = self.shape[name]
+        return self._slice(self.shadow8, name).view(s[0], -1)
+
+    def w_si(self, name):
+        i = self.fp8_names.index(name)
+        return self.w_scale_inv[i:i + 1]
+
+    def refresh_shadow8(self):
+        if self._shadow8_epoch != self.shadow_epoch:
+            ops.fp8_quantize_segments(self.shadow, self.chunk_seg, len(self.fp8_names), self._amax_ws, self.shadow8, self.w_scale_inv)
+            self._shadow8_epoch = self.shadow_epoch
 
     def zero_grads(self):
         self.grads.zero_()
@@ -235,6 +265,28 @@ class PretrainRuntime:
         # per ViT-B B=32 step).  The encoder's stream (5 120 token rows, latency-bound kernels) stays f32.  MOFO_DEC_RESID=f32
         # restores the f32 decoder stream (A/B, parity debugging).
         self.dec_resid = F32 if os.environ.get("MOFO_DEC_RESID", "bf16") == "f32" else BF16
+        # MOFO_FP8=1: the forward Linears fed by a LayerNorm (qkv, fc1) run on OCP e4m3 operands with the block-scaled MFMA
+        # (2x the bf16 MFMA rate; BASELINE configs[4] "fp8 MFMA attention/MLP").  Per-tensor scales: weights from their amax
+        # every time the shadow changes, activations with delayed scaling (a LayerNorm's scale comes from the amax it saw in
+        # the previous forward; the first forward of a runtime is run once more to calibrate).  Backward stays bf16.
+        self.fp8 = os.environ.get("MOFO_FP8", "0") == "1" and not forward_only and top and enc_prefix is not None and dec_prefix is not None
+        if self.fp8:
+            blocks = (self.encW if enc_prefix is not None else []) + (self.decW if dec_prefix is not None else [])
+            names = [n for W in blocks for n in (W.prefix + "attn.qkv.weight", W.prefix + "mlp.fc1.weight")
+                     if store.shape[n][1] % 128 == 0]
+            self.fp8 = bool(names)
+            if self.fp8:
+                store.enable_fp8(names)
+                for W in blocks:
+                    for attr, n in (("qkv8", W.prefix + "attn.qkv.weight"), ("fc18", W.prefix + "mlp.fc1.weight")):
+                        setattr(W, attr, store.b8view(n) if n in names else None)
+                        setattr(W, attr + "_si", store.w_si(n) if n in names else None)
+                nsite = 2 * len(blocks)
+                self.act_scales = torch.tensor([[16.0, 1.0 / 16.0]] * nsite, dtype=F32, device=self.dev)
+                self.act_amax = torch.zeros(nsite, dtype=F32, device=self.dev)
+                for i, W in enumerate(blocks):
+                    W.site = 2 * i
+                self._fp8_calibrated = False
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
@@ -283,7 +335,9 @@ class PretrainRuntime:
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        return NS(xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * H * n, dt=F32),
+        f8 = torch.float8_e4m3fn
+        extra = dict(xln1_8=e(M, D, dt=f8), xln2_8=e(M, D, dt=f8)) if getattr(self, "fp8", False) and D % 128 == 0 else {}
+        return NS(**extra, xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * H * n, dt=F32),
                   x_mid=e(M, D, dt=resid), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
                   x_out=e(M, D, dt=resid))
 
@@ -375,15 +429,26 @@ class PretrainRuntime:
     # ------------------------------------------------------------------ transformer block
     def _block_fwd(self, W, L, x_in, B, n, H):
         eps, scale = self.d.eps, 64 ** -0.5
-        ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
-        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
+        f8 = self.fp8 and getattr(W, "qkv8", None) is not None and hasattr(L, "xln1_8")
+        if f8:
+            sc, am = self.act_scales, self.act_amax
+            ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[W.site, 0:1], am[W.site:W.site + 1])
+            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, L.xln1_8, W.qkv8, L.qkv, bias=W.qkvb, a_scale_inv=sc[W.site, 1:2], b_scale_inv=W.qkv8_si)
+        else:
+            ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
+            ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
         ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse)
         if L.x_mid.dtype == BF16:      # bf16 residual stream (decoder): the residual rides in the GEMM's `aux` operand
             ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.ao, W.proj, L.x_mid, bias=W.projb, aux=x_in)
         else:
             ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
-        ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
-        ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
+        if f8:
+            ops.layernorm_fwd_q(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2, L.xln2_8, sc[W.site + 1, 0:1], am[W.site + 1:W.site + 2])
+            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, L.xln2_8, W.fc18, L.h1, C2=L.g, bias=W.fc1b, a_scale_inv=sc[W.site + 1, 1:2],
+                     b_scale_inv=W.fc18_si)
+        else:
+            ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
+            ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
         if L.x_out.dtype == BF16:
             ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.g, W.fc2, L.x_out, bias=W.fc2b, aux=L.x_mid)
         else:
@@ -663,9 +728,17 @@ class PretrainRuntime:
     def _forward(self, w: NS):
         enc_out = self.encoder_forward(w)
         x_full = self.bridge_forward(w, enc_out)
-        return self.decoder_forward(w, x_full, w.n_msk)
+        out = self.decoder_forward(w, x_full, w.n_msk)
+        if self.fp8:
+            ops.fp8_update_scales(self.act_amax, self.act_scales)      # this forward's amax -> the next forward's scales
+        return out
 
     def forward(self, w: NS):
+        if self.fp8:
+            self.store.refresh_shadow8()
+            if not self._fp8_calibrated:       # delayed scaling needs one look at the activations before the first real step
+                self._fp8_calibrated = True
+                self._forward(w)
         return self.cached(w, ("fwd", getattr(w, "src_u8", False)), lambda: self._forward(w))
 
     def _loss_forward(self, w, normalize_target, grad_scale):

@@ -80,6 +80,88 @@ def test_gemm_nt_epilogues(dev, M, N, K):
         assert _rel(Cf, 2 * ref) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 128, 128), (320, 2304, 768), (77, 192, 256), (640, 3072, 1024), (1000, 1536, 384), (5000, 200, 128)])
+def test_gemm_nt_fp8(dev, M, N, K):
+    """NT on OCP e4m3 operands (block-scaled MFMA with unit block scales, f32 accumulate, per-tensor de-quantisation factors
+    read on the device) against fp32 torch on the SAME quantised operands: only the accumulation order differs."""
+    from mofo_amd import ops
+    F8 = torch.float8_e4m3fn
+    a = torch.randn(M, K, generator=torch.Generator().manual_seed(1)).to(dev) * 1.3
+    w = torch.randn(N, K, generator=torch.Generator().manual_seed(2)).to(dev) * 0.04
+    sa, sw = 448.0 / float(a.abs().max()), 448.0 / float(w.abs().max())
+    A8 = (a * sa).clamp(-448, 448).to(F8)
+    W8 = (w * sw).clamp(-448, 448).to(F8)
+    ai = torch.tensor([1.0 / sa], dtype=F32, device=dev)
+    wi = torch.tensor([1.0 / sw], dtype=F32, device=dev)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    ref = (A8.float() @ W8.float().t()) / (sa * sw)
+    C = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, A8, W8, C, a_scale_inv=ai, b_scale_inv=wi)
+    assert _rel(C, ref) < 5e-3
+    idx = torch.randint(0, M * N, (64,), generator=torch.Generator().manual_seed(5))
+    assert torch.allclose(C.flatten()[idx].float(), ref.flatten()[idx], rtol=2e-2, atol=2e-2)
+    C2 = torch.empty_like(C)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, A8, W8, C, C2=C2, bias=bias, a_scale_inv=ai, b_scale_inv=wi)
+    assert _rel(C, ref + bias) < 5e-3 and _rel(C2, torch.nn.functional.gelu(ref + bias)) < 8e-3
+    # the quantisation itself: against the unquantised product the error is e4m3's (3 mantissa bits on both operands)
+    assert _rel(ref, a @ w.t()) < 6e-2
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, A8[:, :64].contiguous(), W8[:, :64].contiguous(), C, a_scale_inv=ai, b_scale_inv=wi)
+
+
+def test_fp8_quantisation_kernels(dev):
+    """e4m3 quantisation: segmented per-tensor quantisation of a flat bf16 buffer (the weight shadow), the plain form, the
+    LayerNorm that also emits e4m3, and the delayed-scaling update -- against torch's float8_e4m3fn conversion"""
+    from mofo_amd import ops
+    F8 = torch.float8_e4m3fn
+    # three "tensors" in a flat buffer: chunks 0-1 -> segment 0, chunk 2 untouched, chunks 3-5 -> segment 1 (incl. an all-zero tail chunk)
+    flat = _rand((6 * 1024,), dev, 1, 0.05)
+    flat[1024:2048] *= 7.0
+    flat[5 * 1024:] = 0
+    seg = torch.tensor([0, 0, -1, 1, 1, 1], dtype=torch.int16, device=dev)
+    out = torch.zeros(6 * 1024, dtype=F8, device=dev)
+    out.view(torch.uint8)[2048:3072] = 0x5A
+    amax = torch.empty(2, dtype=F32, device=dev)
+    sinv = torch.zeros(2, dtype=F32, device=dev)
+    ops.fp8_quantize_segments(flat, seg, 2, amax, out, sinv)
+    for s_, (lo, hi) in enumerate(((0, 2048), (3072, 6144))):
+        x = flat[lo:hi].float()
+        a = float(x.abs().max())
+        assert float(sinv[s_]) == pytest.approx(a / 448.0, rel=1e-6)
+        want = (x * (448.0 / a)).clamp(-448, 448).to(F8)
+        assert torch.equal(out[lo:hi].view(torch.uint8), want.view(torch.uint8))
+    assert torch.all(out.view(torch.uint8)[2048:3072] == 0x5A)          # a chunk outside every segment is not written
+    # plain tensor with a given scale, amax reported
+    x = _rand((300, 128), dev, 2, 3.0)
+    sc = torch.tensor([20.0], dtype=F32, device=dev)
+    q = torch.empty(300, 128, dtype=F8, device=dev)
+    am = torch.zeros(1, dtype=F32, device=dev)
+    ops.fp8_quantize_bf16(x, sc, q, am)
+    assert torch.equal(q.view(torch.uint8), (x.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))      # saturates, never NaN
+    assert float(am) == float(x.float().abs().max())
+    # LayerNorm + e4m3 copy of the (bf16-rounded) output
+    M, D = 512, 384
+    xs = _rand((M, D), dev, 3, 2.0, F32)
+    w = _rand((D,), dev, 4, 0.3, F32) + 1.0
+    b = _rand((D,), dev, 5, 0.3, F32)
+    y = torch.empty(M, D, dtype=BF16, device=dev)
+    y2 = torch.empty_like(y)
+    mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+    y8 = torch.empty(M, D, dtype=F8, device=dev)
+    am.zero_()
+    ops.layernorm_fwd_q(xs, w, b, 1e-6, y, mean, rstd, y8, sc, am)
+    ops.layernorm_fwd(xs, w, b, 1e-6, y2, mean, rstd)
+    assert torch.equal(y, y2)
+    assert torch.equal(y8.view(torch.uint8), (y.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))
+    assert 0.0 < float(am) <= float(y.float().abs().max())              # a sample of the rows
+    # delayed scaling update
+    amx = torch.tensor([2.0, 0.0], dtype=F32, device=dev)
+    scales = torch.tensor([[16.0, 1 / 16.0], [8.0, 0.125]], dtype=F32, device=dev)
+    ops.fp8_update_scales(amx, scales, margin=1.5)
+    assert scales[0, 0].item() == pytest.approx(448.0 / 3.0) and scales[0, 1].item() == pytest.approx(3.0 / 448.0)
+    assert scales[1].tolist() == [8.0, 0.125] and amx.tolist() == [0.0, 0.0]
+
+
 def test_gemm_nt_pos_rowmap(dev):
     from mofo_amd import ops
     Bc, nv, Ntok, K, N = 3, 20, 50, 128, 192

@@ -666,6 +666,50 @@ def test_vit_large_32_frames_parity(dev):
         assert _rel(g[n], grads[n]) < 6e-2, n
 
 
+def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
+    """BASELINE configs[4] ("ViT-L 32x224x224 ... fp8 MFMA attention/MLP"): MOFO_FP8=1 runs the LayerNorm-fed forward Linears
+    (qkv, fc1) on OCP e4m3 operands with per-tensor scales.  Against the reference classes' fp32 fixture (vitl32.npz) and the
+    bf16 path.  Stated tolerances: e4m3 keeps 3 mantissa bits (2^-4 relative per element), the error of a K = 1024
+    contraction averages down to ~1 % of an output's scale -- loss within 1e-2 of the reference (bf16: 1e-3), gradient norm
+    within 5e-2, and within those bounds of the bf16 path; the weights' e4m3 shadow follows an optimizer step."""
+    from mofo_amd import optim_factory, utils
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=3, enc_heads=16, dec_dim=512, dec_depth=1, dec_heads=8)
+    x = O.keyed_clips(1, cfg).to(dev)
+    np.random.seed(7)
+    mask = torch.from_numpy(O.tube_mask(cfg.grid, 0.9)[None]).bool().to(dev)
+    fx = np.load(os.path.join(G, "vitl32.npz"))
+    out = {}
+    for tag in ("bf16", "fp8"):
+        monkeypatch.setenv("MOFO_FP8", "1" if tag == "fp8" else "0")
+        model, _ = _build(cfg, "xavier", dev)
+        rt = model.runtime()
+        assert rt.fp8 == (tag == "fp8")
+        opt = optim_factory.create_optimizer(_Args, model)
+        scaler = utils.NativeScalerWithGradNormCount()
+        losses, norms = [], []
+        for _ in range(3):
+            loss = model.forward_loss(x, mask)
+            losses.append(float(loss))
+            opt.zero_grad()
+            norms.append(float(scaler(loss, opt, clip_grad=None)))
+        model.check_status()
+        out[tag] = (losses, norms)
+        if tag == "fp8":
+            st = rt.store
+            assert len(st.fp8_names) == 2 * (cfg.enc_depth + cfg.dec_depth)
+            n0 = "encoder.blocks.0.attn.qkv.weight"       # the e4m3 shadow is the quantised CURRENT bf16 shadow
+            wq = st.b8view(n0).float() * st.w_si(n0)
+            assert _rel(wq, st.bview(n0).float()) < 4e-2
+            assert float(rt.act_scales[:, 0].min()) > 1.0 and not torch.equal(rt.act_scales[0], torch.tensor([16.0, 1 / 16.0], device=dev))
+    (lb, nb), (lf, nf) = out["bf16"], out["fp8"]
+    assert lb[0] == pytest.approx(float(fx["loss"]), rel=1e-3)
+    assert lf[0] == pytest.approx(float(fx["loss"]), rel=1e-2) and nf[0] == pytest.approx(float(fx["grad_norm"]), rel=5e-2)
+    np.testing.assert_allclose(lf, lb, rtol=1e-2)
+    np.testing.assert_allclose(nf, nb, rtol=5e-2)
+    assert lf[2] < lf[0]
+
+
 # ----------------------------------------------------------------------------- "next" rows (SURVEY.md 8f-4)
 def _tiny(mode, dev):
     from oracle import pretrain_oracle as O
