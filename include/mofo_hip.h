@@ -125,6 +125,10 @@ int mofo_attention_delta_zero_dq(const void* out, int ldo, const void* dout, int
 int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
 
+/* zero the listed 1024-element chunks of a flat f32 buffer (optimizer.zero_grad() over the gradient ranges the next backward
+ * accumulates into; the ranges it overwrites are skipped).  chunk_ids: device int32 [n]. */
+int mofo_zero_chunks(float* base, const int* chunk_ids, int n, void* stream);
+
 /* ---- OCP e4m3 quantisation for MOFO_GEMM_NT_FP8 (per-tensor scales; BASELINE configs[4]).
  * segments: x is a flat bf16 buffer of n = 1024 * chunks elements; chunk_seg[c] names the tensor ("segment", 0..nseg-1) chunk c
  * belongs to, or -1 (left untouched).  Per segment: amax -> out = sat_e4m3(x * 448 / amax), scale_inv[seg] = amax / 448.

@@ -63,6 +63,7 @@ _SIGS = {
     "mofo_adamw_blocks": (_i, [_ll]),
     "mofo_norm_finalize": (_i, [_vp, _i, _vp, _vp]),
     "mofo_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+    "mofo_zero_chunks": (_i, [_vp, _vp, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)
 

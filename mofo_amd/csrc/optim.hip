@@ -146,3 +146,19 @@ extern "C" int mofo_cast_bf16(const float* src, void* dst, long long n, void* st
     MOFO_CHECK_LAUNCH("mofo_cast_bf16");
     return MOFO_OK;
 }
+
+// zero_grad over the parts of the flat gradient buffer that the next backward ACCUMULATES into (atomic split-K / bias /
+// LayerNorm partial sums); the weight gradients it overwrites with plain stores are skipped (runtime.FlatStore.zero_grads):
+// one block per listed 1024-element chunk.  Replaces a 377 MB fill by ~45 MB at ViT-B.
+namespace {
+__global__ __launch_bounds__(256) void zero_chunks_kernel(float* __restrict__ base, const int* __restrict__ chunk_ids) {
+    *(f32x4*)(base + (size_t)chunk_ids[blockIdx.x] * 1024 + threadIdx.x * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+}  // namespace
+
+extern "C" int mofo_zero_chunks(float* base, const int* chunk_ids, int n, void* stream) {
+    if (!base || !chunk_ids || n <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_zero_chunks: bad arguments");
+    hipLaunchKernelGGL(zero_chunks_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, base, chunk_ids);
+    MOFO_CHECK_LAUNCH("mofo_zero_chunks");
+    return MOFO_OK;
+}

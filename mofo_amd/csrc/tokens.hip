@@ -139,9 +139,10 @@ __global__ __launch_bounds__(256) void fill_mask_kernel(const float* __restrict_
 
 // 256 threads = CT column threads (one float4 each, CT = D/4 rounded up to a power-of-two divisor of 256) x RL row lanes;
 // a block covers RB rows; the masked rows' column sums are reduced over the row lanes in LDS, one atomic per column.
-// RB rows per block: few blocks => few adders on the same D addresses of d_mask_token (contended same-address f32 atomics
-// run ~14x below the atomic rate); 256 rows x D x 2 B per block still leaves ~800 blocks at ViT-B, B=32.
-constexpr int RB = 256;
+// RB rows per block: fewer blocks => fewer adders on the same D addresses of d_mask_token (contended same-address f32 atomics
+// run ~14x below the atomic rate), but 256 rows per block left 196 blocks for the 50 176 rows of ViT-B, B=32 -- less than one
+// per CU, 78 us for 38.5 MB.  64 rows: 784 blocks, 784 adds per address (~10 us of serialised atomics, under the read time).
+constexpr int RB = 64;
 template <bool BF16IN>
 __global__ __launch_bounds__(256) void assemble_bwd_kernel(const void* __restrict__ dxv, int N, int n_vis, int D, int rows, int ct,
                                                            bf16_t* __restrict__ d_e2d, float* __restrict__ d_mask_token) {

@@ -590,3 +590,11 @@ def cast_bf16(src, dst):
         raise ValueError("cast_bf16: length mismatch")
     _run("mofo_cast_bf16", ("cast",), 6.0 * src.numel(), _p(src), _p(dst), src.numel())
     return dst
+
+
+def zero_chunks(buf, chunk_ids):
+    """zero the listed 1024-element chunks of a flat f32 buffer (chunk_ids: int32 GPU tensor)"""
+    _chk(buf, F32, "buf", 1), _chk(chunk_ids, I32, "chunk_ids", 1)
+    if buf.numel() % 1024 or chunk_ids.numel() == 0:
+        raise ValueError("zero_chunks: buffer of whole 1024-element chunks, non-empty list")
+    _run("mofo_zero_chunks", ("zero_grad",), 4096.0 * chunk_ids.numel(), _p(buf), _p(chunk_ids), chunk_ids.numel())
