@@ -110,14 +110,23 @@ def main():
     import torch.distributed as dist
     force_dp = os.environ.get("MOFO_FORCE_DP") == "1" and "MASTER_ADDR" in os.environ
     if world > 1 or force_dp:
-        if backend == "nccl":
-            dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
-        else:
-            dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
-        # the communicator really spans `world` ranks: a SUM all-reduce of ones (run_mae_pretraining.py:225-227's group)
-        ones = torch.ones(1, dtype=torch.float32, device=dev)
-        dist.all_reduce(ones)
-        rccl_ranks = int(round(float(ones.item())))
+        # RCCL prints a version banner on STDOUT when its first communicator comes up: keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            if backend == "nccl":
+                dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
+            else:
+                dist.init_process_group(backend, init_method="env://", world_size=world, rank=rank)
+            # the communicator really spans `world` ranks: a SUM all-reduce of ones (run_mae_pretraining.py:225-227's group)
+            ones = torch.ones(1, dtype=torch.float32, device=dev)
+            dist.all_reduce(ones)
+            rccl_ranks = int(round(float(ones.item())))
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+            os.close(saved_stdout)
         if rccl_ranks != dist.get_world_size() or rccl_ranks != world:
             raise SystemExit(f"collective backend '{backend}' sees {rccl_ranks} ranks, expected {world}")
     else:
