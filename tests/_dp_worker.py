@@ -111,10 +111,25 @@ def main():
         ref_model = build(cfg, dev)
         ref_losses, ref_params, ref_grads, ref_norms, ref_generic = train(ref_model, ref_model, x_all.to(dev), mask_all.to(dev), steps, labels_all)
         rel = lambda a, b: float((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm())
+        # ... and against the CPU ORACLE on the whole global batch from rank 0's initial weights: first-step loss, global gradient
+        # norm and the flat gradient tensor by tensor (the data-parallel MEAN gradient = the whole-batch gradient)
+        torch.manual_seed(100)
+        P0 = {k: v.detach().cpu().float().clone() for k, v in build(cfg, dev).state_dict().items()}
+        o_loss, o_norm, o_grads = O.train_step(x_all, mask_all, P0, cfg)
+        st = model.runtime().store
+        worst = 0.0
+        total = float(torch.sqrt(sum(g.double().pow(2).sum() for g in o_grads.values())))
+        for n, g in o_grads.items():
+            if float(g.double().norm()) < 2e-3 * total:
+                continue
+            o, k = st.offset[n], g.numel()
+            worst = max(worst, rel(grads[o:o + k], g.reshape(-1)))
         json.dump({"world": world, "segments": n_seg, "losses": all_losses, "ref_losses": ref_losses,
                    "rank_param_diff": [rel(g, gathered[0]) for g in gathered], "params_vs_single_process": rel(gathered[0], ref_params),
                    "grads_vs_single_process": rel(grads, ref_grads), "norms": norms, "ref_norms": ref_norms,
-                   "generic_grads_vs_single_process": rel(generic, ref_generic), "backend": backend}, open(out_path, "w"))
+                   "generic_grads_vs_single_process": rel(generic, ref_generic), "backend": backend,
+                   "oracle_loss": float(o_loss), "oracle_grad_norm": float(o_norm), "grads_vs_oracle_worst_tensor": worst,
+                   "grad_norm_step1": float(grads.double().norm())}, open(out_path, "w"))
     dist.barrier()
     dist.destroy_process_group()
 

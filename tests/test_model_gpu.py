@@ -229,7 +229,16 @@ def test_vitb_engine_step_parity(dev):
         if ref > 1e-3 * float(g["grad_norm"]):
             worst = max(worst, abs(got - ref) / ref)
             assert got == pytest.approx(ref, rel=5e-2), n
-        n16 = min(16, grads[n].numel())
+    # element-wise, against the oracle's gradients (the oracle's per-tensor gradient statistics are pinned to the reference's
+    # at 1e-3 by test_oracle_golden.py): the first and last encoder block, a decoder block, the tubelet embedding, the head
+    got_g = {n: grads[n].detach().float().cpu().clone() for n in
+             ("encoder.patch_embed.proj.weight", "encoder.blocks.0.attn.qkv.weight", "encoder.blocks.11.mlp.fc1.weight",
+              "encoder.blocks.11.attn.proj.weight", "encoder_to_decoder.weight", "decoder.blocks.2.mlp.fc2.weight",
+              "decoder.blocks.0.attn.qkv.weight", "decoder.head.weight", "decoder.norm.weight", "mask_token")}
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    _, _, oracle_g = O.train_step(x, mask, P, O.VIT_B)
+    for n, gv in got_g.items():
+        assert _rel(gv, oracle_g[n]) < 6e-2, n
     w = model.runtime().ws(2, 160)
     assert _rel(w.pred.view(2, 1408, 1536)[:, :6, :48], g["out_slice"]) < 2e-2
     sd = model.state_dict()
@@ -606,6 +615,11 @@ def test_ranks_share_one_gpu_like_the_multi_gpu_job(dev, tmp_path, world):
     assert max(res["rank_param_diff"]) == 0.0                         # replicas stay bit-identical (same reduced gradients, same update)
     assert res["grads_vs_single_process"] < 2e-2                      # all-reduced shard gradients = the whole-batch gradient (bf16 noise)
     assert res["generic_grads_vs_single_process"] < 2e-2              # ... also through model(x, mask) + nn.MSELoss (mean, not world x mean)
+    # against the CPU oracle on the whole global batch (not only HIP vs HIP): mean of the ranks' first-step losses, the norm of
+    # the all-reduced gradient, and that gradient tensor by tensor
+    assert float(np.mean([l[0] for l in res["losses"]])) == pytest.approx(res["oracle_loss"], rel=1e-3)
+    assert res["grad_norm_step1"] == pytest.approx(res["oracle_grad_norm"], rel=2e-2)
+    assert res["grads_vs_oracle_worst_tensor"] < 6e-2
     assert res["params_vs_single_process"] < 2e-2                     # ... and so is the trajectory (Adam amplifies noise on tiny gradients)
     mean_losses = np.mean(np.array(res["losses"]), axis=0)            # mean of the ranks' shard losses = loss of the whole batch
     np.testing.assert_allclose(mean_losses, res["ref_losses"], rtol=2e-3)
