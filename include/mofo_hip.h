@@ -125,6 +125,17 @@ int mofo_attention_delta_zero_dq(const void* out, int ldo, const void* dout, int
 int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
 
+/* ---- RCCL communicator: the stand-alone route to the ONE collective of the path -- the per-step gradient
+ * all-reduce of run_mae_pretraining.py:225-227 (DDP) over the group of utils.py:289-294 -- for callers that bind this library
+ * without torch.distributed (mofo_amd/dist.py itself uses torch.distributed's "nccl" = RCCL backend).  librccl is opened at
+ * run time.  Rank 0 calls mofo_comm_unique_id and hands the 128 bytes to the other ranks by its own means (file, env, TCP);
+ * every rank then calls mofo_comm_init (a collective) with HIP's current device = its GPU.  The handle is owned by the library.
+ * mofo_comm_allreduce_f32: in-place SUM over the ranks, enqueued on `stream` (pre-scale by 1/world for DDP's mean). */
+int mofo_comm_unique_id(void* id128);
+int mofo_comm_init(const void* id128, int rank, int world, void** comm_out);
+int mofo_comm_allreduce_f32(void* comm, float* buf, long long n, void* stream);
+int mofo_comm_destroy(void* comm);
+
 /* zero the listed 1024-element chunks of a flat f32 buffer (optimizer.zero_grad() over the gradient ranges the next backward
  * accumulates into; the ranges it overwrites are skipped).  chunk_ids: device int32 [n]. */
 int mofo_zero_chunks(float* base, const int* chunk_ids, int n, void* stream);

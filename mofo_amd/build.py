@@ -9,7 +9,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmofo_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-SOURCES = ["gemm.hip", "attention.hip", "layernorm.hip", "tokens.hip", "loss.hip", "optim.hip", "quant.hip", "capi.cpp"]
+SOURCES = ["gemm.hip", "attention.hip", "layernorm.hip", "tokens.hip", "loss.hip", "optim.hip", "quant.hip", "capi.cpp", "comm.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast", "-Wall", "-Wno-unused-function",
          # keep MFMA accumulators in arch VGPRs: with the default AGPR form hipcc (ROCm 7.2) copied every accumulator in
          # and out of the AGPR file each loop iteration (100 v_accvgpr_* per 16 MFMAs in the GEMM main loop)
@@ -46,7 +46,7 @@ def build(force=False, verbose=False):
         list(ex.map(run, jobs))
     objs = [os.path.join(objdir, s + ".o") for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"])
     return LIB
 
 

@@ -86,3 +86,41 @@ class DataParallel(torch.nn.Module):
     def forward_loss(self, x, mask, normlize_target=True, grad_scale=None):
         gs = 1.0 / self.world_size if grad_scale is None else grad_scale
         return self.module.forward_loss(x, mask, normlize_target, gs)
+
+
+class NativeComm:
+    """The C-ABI's own RCCL communicator (include/mofo_hip.h: mofo_comm_*), for callers that do not bring up
+    torch.distributed: ``NativeComm.unique_id()`` on rank 0 -> 128 bytes handed to every rank by the caller's means ->
+    ``NativeComm(id, rank, world)`` on each rank (with torch.cuda.set_device done) -> ``all_reduce_(flat_f32)`` on the
+    current stream.  mofo_amd's own training path (GradSync above) uses torch.distributed's RCCL backend instead."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib.load()
+        self.rank, self.world = rank, world
+        h = C.c_void_p()
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        _lib.check(self._lib.mofo_comm_init(buf, rank, world, C.byref(h)), "mofo_comm_init")
+        self._h = h
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes as C
+        from . import _lib
+        buf = C.create_string_buffer(128)
+        _lib.check(_lib.load().mofo_comm_unique_id(buf), "mofo_comm_unique_id")
+        return buf.raw
+
+    def all_reduce_(self, t: torch.Tensor):
+        from . import _lib
+        if not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous():
+            raise ValueError("all_reduce_: contiguous f32 GPU tensor")
+        _lib.check(self._lib.mofo_comm_allreduce_f32(self._h, t.data_ptr(), t.numel(), torch.cuda.current_stream().cuda_stream), "mofo_comm_allreduce_f32")
+        return t
+
+    def close(self):
+        from . import _lib
+        if self._h is not None:
+            _lib.check(self._lib.mofo_comm_destroy(self._h), "mofo_comm_destroy")
+            self._h = None

@@ -591,6 +591,24 @@ def test_gradient_sync_on_one_rank_rccl(dev):
         os.environ.pop("MOFO_FORCE_DP", None)
 
 
+def test_native_rccl_communicator(dev):
+    """include/mofo_hip.h mofo_comm_*: the C-ABI's own RCCL communicator (librccl opened at run time).  One rank here (RCCL
+    refuses two ranks on one device): unique id -> init -> in-place SUM all-reduce on the current stream -> destroy."""
+    from mofo_amd.dist import NativeComm
+    uid = NativeComm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = NativeComm(uid, 0, 1)
+    g = torch.arange(5000, dtype=torch.float32, device=dev) * 0.5
+    want = g.clone()
+    comm.all_reduce_(g)
+    torch.cuda.synchronize()
+    assert torch.equal(g, want)                                        # SUM over one rank
+    with pytest.raises(ValueError):
+        comm.all_reduce_(g.to(torch.bfloat16))
+    comm.close()
+    comm.close()                                                       # idempotent
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_ranks_share_one_gpu_like_the_multi_gpu_job(dev, tmp_path, world):
     """The N > 1 job rehearsed on the one GPU of this box: ``world`` processes under torch.distributed.run (tests/_dp_worker.py),
