@@ -10,6 +10,9 @@ import torch  # noqa: F401  (loads libamdhip64 before our library)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmofo_hip.so")
+# measurement only (tools/attn_ab.py, same-box A/B of two builds): MOFO_HIP_LIB points the loader at another build of the library
+if os.environ.get("MOFO_HIP_LIB"):
+    LIB_PATH = os.path.abspath(os.environ["MOFO_HIP_LIB"])
 
 # enums (mirror include/mofo_hip.h)
 GEMM_NT, GEMM_NN, GEMM_TN, GEMM_NT_FP8 = 0, 1, 2, 3

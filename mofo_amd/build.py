@@ -16,6 +16,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=f
          "-mllvm", "-amdgpu-mfma-vgpr-form"]
 
 
+# attention.hip: no SLP vectorisation.  hipcc packs neighbouring f32 multiplies of MFMA accumulator registers into v_pk_mul_f32
+# plus v_mov shuffles; a packed f32 op issues in two passes anyway (guide MI355X_MICROARCH.md: an anti-lever beside MFMAs), and
+# these kernels are bound by the SIMD's vector issue port.  (Inline-asm single multiplies are not an option: an asm VALU that
+# reads an MFMA result gets none of the compiler's hazard wait states -- it read stale accumulators.)
+EXTRA_FLAGS = {"attention.hip": ["-fno-slp-vectorize"]}
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True
@@ -32,7 +39,7 @@ def build(force=False, verbose=False):
         sp = os.path.join(CSRC, src)
         op = os.path.join(objdir, src + ".o")
         if force or _stale(op, [sp] + headers):
-            cmd = [HIPCC] + FLAGS + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
+            cmd = [HIPCC] + FLAGS + EXTRA_FLAGS.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", op]
             jobs.append(cmd)
     def run(cmd):
         if verbose:

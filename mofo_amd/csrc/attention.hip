@@ -48,6 +48,13 @@ __device__ unsigned long long g_attn_trace[1 << 18];
 #define OP_STAMP_FLUSH()
 #endif
 
+// raised priority while a wave issues its MFMA groups: the matrix pipe is fed first, other waves' VALU fills the issue gaps
+#ifdef MOFO_ATTN_NOPRIO
+#define ATTN_PRIO(x)
+#else
+#define ATTN_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
+
 constexpr int HD = 64;
 constexpr int RS = 128;              // LDS row stride in bytes (no padding)
 constexpr int TILE = 32 * RS;        // one 32-row tile
@@ -132,11 +139,11 @@ __device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int&
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
 // and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
-template <int NW, int MODE, bool WHOLE>
+template <int NW, int MODE, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
-                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta) {
+                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta, float thr) {
     constexpr int NBUF = WHOLE ? 5 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -202,14 +209,17 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 
     // the tile body is instantiated twice: full tiles carry NO masking code; only a ragged last tile pays for the
     // per-element key-index compare / select (the single-version loop spent ~64 VALU per tile on it)
-    auto tile = [&](int kt, auto masked_tag) {
+    auto tile = [&](int kt, auto masked_tag, auto parity_tag) {
         constexpr bool MASKED = decltype(masked_tag)::value;
-        const unsigned char* Kt = smem + (WHOLE ? kt : (kt & 1)) * 2 * TILE;
+        constexpr int PAR = decltype(parity_tag)::value;       // -1: buffer parity from kt at run time
+        const unsigned char* Kt = smem + (WHOLE ? kt : (PAR >= 0 ? PAR : (kt & 1))) * 2 * TILE;
         const unsigned char* Vt = Kt + TILE;
         ATTN_STAMP(kt, 0);
         f32x16 s = zero16();
+        ATTN_PRIO(1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Kt, ks, lane), qf[ks], s, 0, 0, 0);
+        ATTN_PRIO(0);
         ATTN_STAMP(kt, 1);
         float p[16];
         if constexpr (MODE == 0) {
@@ -223,7 +233,9 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            const float mn = fmaxf(m, mx);
+            // lazy rescale (guide T13): the reference max of a row moves only when the tile max exceeds it by more than thr
+            // (log2 units), so p <= 2^thr instead of <= 1 and the O-wide rescale pass runs in the first tile(s) only
+            const float mn = (mx - m) * c > thr ? mx : m;
             const float nmc = -mn * c;
             float ls = 0.f;
 #pragma unroll
@@ -244,14 +256,18 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             m = mn;
             const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
             ATTN_STAMP(kt, 2);
+            ATTN_PRIO(1);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 0, lane), pf0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 0, lane), pf1, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 1, lane), pf0, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 1, lane), pf1, o1, 0, 0, 0);
+            ATTN_PRIO(0);
         } else {
             f32x16 dp = zero16();
+            ATTN_PRIO(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, ks, lane), dof[ks], dp, 0, 0, 0);
+            ATTN_PRIO(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pr = fast_exp2(fmaf(s[r], c, -L2));
@@ -262,14 +278,16 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             }
             const bf16x8 f0 = pack_frag(p, 0), f1 = pack_frag(p, 1);
             ATTN_STAMP(kt, 2);
+            ATTN_PRIO(1);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 0, lane), f0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 0, lane), f1, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 0, 1, lane), f0, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kt, 1, 1, lane), f1, o1, 0, 0, 0);
+            ATTN_PRIO(0);
         }
         ATTN_STAMP(kt, 3);
         if constexpr (!WHOLE) {
-            if (kt + 1 < nkt) lwrite((kt + 1) & 1);
+            if (kt + 1 < nkt) lwrite(PAR >= 0 ? (PAR ^ 1) : ((kt + 1) & 1));
             ATTN_STAMP(kt, 4);
             __syncthreads();
             ATTN_STAMP(kt, 5);
@@ -278,8 +296,20 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         ATTN_STAMP(kt, 6);
     };
     const int nfull = N >> 5;
-    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
-    if (nfull < nkt) tile(nfull, std::true_type{});
+    using NoPar = std::integral_constant<int, -1>;
+    if constexpr (U2 && !WHOLE) {
+        // two tiles per iteration with the LDS buffer parity at compile time: every ds_read address is a hoisted lane
+        // offset + an immediate, no per-tile address VALU
+        int kt = 0;
+        for (; kt + 1 < nfull; kt += 2) {
+            tile(kt, std::false_type{}, std::integral_constant<int, 0>{});
+            tile(kt + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        }
+        if (kt < nfull) tile(kt, std::false_type{}, NoPar{});
+    } else {
+        for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, NoPar{});
+    }
+    if (nfull < nkt) tile(nfull, std::true_type{}, NoPar{});
 
     if (!qvalid) return;
     if constexpr (MODE == 0) {
@@ -293,11 +323,15 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ dK, dV
-template <int NW, bool WHOLE>
+// Measured on the decoder shape (tools/attn_ab.py, one process): two-tile unrolling with compile-time buffer parity -4.9 %;
+// raised MFMA priority here +5 % (two waves per SIMD: the partner's VALU is what overlaps); -delta pre-loaded into the dP
+// accumulators instead of 16 subtractions +7 % (the dP chain then starts behind an LDS round trip).
+template <int NW, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
                                                             bf16_t* __restrict__ dqkv, int lddqkv) {
+    constexpr bool PRELOAD = U2;
     // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
     constexpr int BUF = 2 * TILE + 256;
     constexpr int NBUF = WHOLE ? 5 : 2;
@@ -363,20 +397,41 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         if (nqt > 1) gload(1);
     }
 
-    for (int qt = 0; qt < nqt; ++qt) {
-        const unsigned char* Qt = smem + (WHOLE ? qt : (qt & 1)) * BUF;
+    auto qtile = [&](int qt, auto parity_tag) {
+        constexpr int PAR = decltype(parity_tag)::value;       // -1: buffer parity from qt at run time
+        const unsigned char* Qt = smem + (WHOLE ? qt : (PAR >= 0 ? PAR : (qt & 1))) * BUF;
         const unsigned char* Ot = Qt + TILE;
         const float* Lt = (const float*)(Qt + 2 * TILE);
         const float* Dt = Lt + 32;
         f32x16 s = zero16(), dpv = zero16();
+        f32x4 lvs[4];
+        if constexpr (PRELOAD) {
+            // all eight row fragments in flight before the first MFMA: hipcc otherwise re-used one fragment register and
+            // put a full LDS round trip (ds_read -> lgkmcnt(0)) in front of each of the 8 chained MFMAs
+            bf16x8 qa[4], oa[4];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), kf[ks], s, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) qa[ks] = row_frag(Qt, ks, lane);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
+            for (int ks = 0; ks < 4; ++ks) oa[ks] = row_frag(Ot, ks, lane);
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) lvs[rg] = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[ks], vf[ks], dpv, 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), kf[ks], s, 0, 0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
+        }
         float p[16], ds[16];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+            f32x4 lv;
+            if constexpr (PRELOAD) lv = lvs[rg];
+            else lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
             const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -397,10 +452,21 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
         if constexpr (!WHOLE) {
-            if (qt + 1 < nqt) lwrite((qt + 1) & 1);
+            if (qt + 1 < nqt) lwrite(PAR >= 0 ? (PAR ^ 1) : ((qt + 1) & 1));
             __syncthreads();
             if (qt + 2 < nqt) gload(qt + 2);
         }
+    };
+    using NoPar = std::integral_constant<int, -1>;
+    if constexpr (U2 && !WHOLE) {
+        int qt = 0;
+        for (; qt + 1 < nqt; qt += 2) {
+            qtile(qt, std::integral_constant<int, 0>{});
+            qtile(qt + 1, std::integral_constant<int, 1>{});
+        }
+        if (qt < nqt) qtile(qt, NoPar{});
+    } else {
+        for (int qt = 0; qt < nqt; ++qt) qtile(qt, NoPar{});
     }
     if (ki >= N) return;
     bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
@@ -913,6 +979,14 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 }
 
+// Forward softmax: a row's reference maximum moves only when a tile's maximum exceeds it by more than this many log2 units
+// (p <= 2^thr instead of <= 1; guide T13).  MOFO_ATTN_RESCALE_THR=0 restores the rescale-on-every-new-maximum form (tests
+// compare both); read per launch.
+float rescale_thr() {
+    const char* e = getenv("MOFO_ATTN_RESCALE_THR");
+    return e ? (float)atof(e) : 6.0f;
+}
+
 int pick_nw(int N) {
     static int forced = -1;
     if (forced < 0) {
@@ -926,11 +1000,11 @@ int pick_nw(int N) {
 }
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true); } else { LAUNCH_Q_(NW, MODE, false); } } while (0)
-#define LAUNCH_Q_(NW, MODE, WH)                                                                                         \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
+#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false); } else { LAUNCH_Q_(NW, MODE, false, true); } } while (0)
+#define LAUNCH_Q_(NW, MODE, WH, U2)                                                                                     \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
-                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta)
+                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr())
 
 static int check_common(const char* who, const void* qkv, int ldqkv, int B, int N, int H) {
     if (!qkv) MOFO_FAIL(MOFO_EINVAL, "%s: null qkv", who);
@@ -1034,9 +1108,9 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
-#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true); } else { LAUNCH_KV_(NW, false); } } while (0)
-#define LAUNCH_KV_(NW, WH)                                                                                             \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
+#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, false); } else { LAUNCH_KV_(NW, false, true); } } while (0)
+#define LAUNCH_KV_(NW, WH, U2)                                                                                         \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
     switch (pick_nw(N)) {
