@@ -173,8 +173,12 @@ int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int
 int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx,
                           int B, int N, int n_vis, int D, void* x_full, int x_is_bf16, void* stream);
 /* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows.
- * dx_full is f32 (dx_is_bf16 = 0) or bf16 (1). */
-int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token, void* stream);
+ * dx_full is f32 (dx_is_bf16 = 0) or bf16 (1).  partial_ws: mofo_assemble_bwd_blocks(B, N) * D floats of scratch for the
+ * blocks' column sums (a second small launch adds them), or NULL: every block then adds to d_mask_token with atomics
+ * (same-address adds serialise at ~115 ns each: 95 us instead of ~20 at ViT-B, B = 32). */
+int mofo_assemble_bwd_blocks(int B, int N);
+int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token,
+                      float* partial_ws, void* stream);
 
 /* ---- reconstruction target + MSE: engine_for_pretraining.py:43-63 (un-normalise, patchify (p0 p1 p2) c,
  * per-(token,channel) standardise with UNBIASED var and 1e-6 after the sqrt, gather masked) and :27,67 (nn.MSELoss).

@@ -325,7 +325,8 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 // ------------------------------------------------------------------------------------------------ dK, dV
 // Measured on the decoder shape (tools/attn_ab.py, one process): two-tile unrolling with compile-time buffer parity -4.9 %;
 // raised MFMA priority here +5 % (two waves per SIMD: the partner's VALU is what overlaps); -delta pre-loaded into the dP
-// accumulators instead of 16 subtractions +7 % (the dP chain then starts behind an LDS round trip).
+// accumulators instead of 16 subtractions +7 % (the dP chain then starts behind an LDS round trip); capped at 168 VGPRs for a
+// third wave per SIMD (216 needed): 30-48 spills, +21 % / 2.1x.
 template <int NW, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,

@@ -454,7 +454,11 @@ def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
          _p(x_full), xb)
 
 
-def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
+def assemble_bwd_blocks(B, N):
+    return _lib.load().mofo_assemble_bwd_blocks(B, N)
+
+
+def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token, partial_ws=None):
     if dx_full is None or dx_full.dtype not in (F32, BF16):
         raise TypeError("dx_full must be f32 or bf16")
     _chk(dx_full, dx_full.dtype, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2), _chk(d_mask_token, F32, "d_mask_token")
@@ -462,7 +466,12 @@ def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token):
     if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or d_mask_token.numel() != D:
         raise ValueError("assemble_bwd: shape mismatch")
     isb = 1 if dx_full.dtype == BF16 else 0
-    _run("mofo_assemble_bwd", ("assemble_bwd",), (2.0 if isb else 4.0) * B * N * D, _p(dx_full), isb, B, N, n_vis, D, _p(d_e2d), _p(d_mask_token))
+    if partial_ws is not None:
+        _chk(partial_ws, F32, "partial_ws")
+        if partial_ws.numel() < assemble_bwd_blocks(B, N) * D:
+            raise ValueError("assemble_bwd: partial_ws needs assemble_bwd_blocks(B, N) * D floats")
+    _run("mofo_assemble_bwd", ("assemble_bwd",), (2.0 if isb else 4.0) * B * N * D, _p(dx_full), isb, B, N, n_vis, D, _p(d_e2d), _p(d_mask_token),
+         _p(partial_ws))
 
 
 def target_mse(clips, pt, p, msk_idx, pred, normalize, grad_scale, row_loss, loss, dpred=None, target_out=None):

@@ -419,6 +419,7 @@ class PretrainRuntime:
                 w.row_loss = e(Mm, dt=F32)
                 w.loss = torch.zeros(1, dtype=F32, device=dev)
                 w.d_e2d = e(B * n_vis, d.dec_dim)
+                w.asm_partial = e(ops.assemble_bwd_blocks(B, N) * d.dec_dim, dt=F32)   # column sums of d(mask_token), per block
         self._ws[key] = w
         return w
 
@@ -708,7 +709,7 @@ class PretrainRuntime:
 
     def bridge_backward(self, w: NS, dx_full: torch.Tensor, enc_out_bf16: torch.Tensor):
         d, s = self.d, self.store
-        ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, s.gview("mask_token").view(-1))
+        ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, s.gview("mask_token").view(-1), partial_ws=w.asm_partial)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, w.d_e2d, s.bview("encoder_to_decoder.weight"), w.d_encout)
         self._wgrad(w.d_e2d, enc_out_bf16, s.g2d("encoder_to_decoder.weight"))
         return w.d_encout

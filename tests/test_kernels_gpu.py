@@ -448,6 +448,44 @@ def test_attention_fwd_bwd(dev, B, N, H):
     assert torch.allclose(delta, want, rtol=1e-4, atol=1e-4)
 
 
+def test_attention_fwd_lazy_rescale_branch(dev, monkeypatch):
+    """The forward kernel moves a row's reference maximum only when a tile's maximum exceeds it by more than
+    MOFO_ATTN_RESCALE_THR log2 units (default 6).  Random data never takes that branch after the first tile, so the input
+    FORCES it: chosen keys in late tiles (5, 23, 40 and the ragged last one) line up with chosen queries, scores jump by 20 to 60
+    log2 units there.  Checked against fp32 torch on the full tensors, and threshold 0 (rescale on every new maximum) against
+    the shipped threshold; rows below the threshold keep p <= 2^6 and must agree as well."""
+    from mofo_amd import ops
+    B, N, H = 2, 1568 - 7, 2
+    D = H * 64
+    scale = 0.125
+    qkv = _rand((B * N, 3 * D), dev, 11, 1.0).float()
+    q = qkv[:, :D].view(B, N, H, 64)
+    k = qkv[:, D:2 * D].view(B, N, H, 64)
+    for j, (row, key, mul) in enumerate(((3, 5 * 32 + 7, 3.0), (40, 23 * 32 + 1, 5.0), (700, 40 * 32 + 31, 4.0), (1500, N - 1, 6.0), (N - 1, 48 * 32, 2.5))):
+        k[j % B, key, j % H] = q[j % B, row, j % H] * mul          # score = mul * |q|^2 * scale: far above every other key of that row
+    # mild growth below the threshold on other rows: a later key scores ~3 log2 units above the first tiles' maximum
+    k[0, 30 * 32 + 5, 0] = q[0, 100, 0] * 0.35
+    qkv = qkv.to(BF16)
+    x = qkv.float().requires_grad_(True)
+    ref, s = _attn_ref(x, B, N, H, scale)
+    lse_ref = (torch.logsumexp(s, -1) * 1.4426950408889634).detach()
+    outs = {}
+    for thr in ("0", "6"):
+        monkeypatch.setenv("MOFO_ATTN_RESCALE_THR", thr)
+        out = torch.empty(B * N, D, dtype=BF16, device=dev)
+        lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+        ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
+        outs[thr] = (out.float(), lse2.view(B, H, N).clone())
+    for thr in ("0", "6"):
+        out, lse2 = outs[thr]
+        assert torch.isfinite(out).all() and torch.isfinite(lse2).all(), thr
+        assert _rel(out, ref) < 8e-3, thr
+        assert (out - ref.detach()).abs().max() < 0.06, thr          # every row, not just on average: a mis-scaled row is off by O(1)
+        assert torch.allclose(lse2, lse_ref, atol=2e-2, rtol=1e-3), thr
+    assert (outs["0"][0] - outs["6"][0]).abs().max() < 0.04
+    assert torch.allclose(outs["0"][1], outs["6"][1], atol=1e-3, rtol=1e-5)
+
+
 @pytest.mark.parametrize("B,N,H", [(1, 1568, 6), (1, 224, 2), (2, 500, 2), (1, 3136, 1), (3, 190, 1)])
 def test_attention_bwd_onepass(dev, B, N, H):
     """the one-pass backward (key-strip blocks, Latin-square pairs, dQ strips added by packed-bf16 atomics) against fp32
@@ -656,6 +694,15 @@ def test_assemble_fwd_bwd(dev):
     ops.assemble_bwd(dxh, nv, de, dt)
     assert torch.equal(de.view(Bc, nv, D), dxh[:, :nv])
     assert _rel(dt, dxh[:, nv:].float().sum((0, 1))) < 1e-5
+    # the two-launch form: block partials in a workspace instead of same-address atomics (what the runtime uses)
+    ws = torch.full((ops.assemble_bwd_blocks(Bc, N) * D,), float("nan"), dtype=F32, device=dev)
+    for src in (dx, dxh):
+        de.zero_(), dt.fill_(1.0)
+        ops.assemble_bwd(src, nv, de, dt, partial_ws=ws)
+        assert torch.equal(de.view(Bc, nv, D), src[:, :nv].to(BF16))
+        assert _rel(dt - 1.0, src[:, nv:].float().sum((0, 1))) < 1e-5
+    with pytest.raises(ValueError):
+        ops.assemble_bwd(dx, nv, de, dt, partial_ws=ws[:-1])
 
 
 @pytest.mark.parametrize("cfgname,normalize", [("TINY", True), ("VIT_B", True), ("VIT_B", False)])

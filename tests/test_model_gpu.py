@@ -624,9 +624,12 @@ def test_ranks_share_one_gpu_like_the_multi_gpu_job(dev, tmp_path, world):
     # one GPU per rank over RCCL where the box has them (the real exchange: stream-ordered wait(), dmabuf IPC); else all ranks on cuda:0 over gloo
     backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MOFO_DP_TEST_BACKEND": backend}
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(root, "tests", "_dp_worker.py"), out],
-                       capture_output=True, text=True, timeout=900, env=env)
+    for attempt in range(3):     # a port picked as free can be taken before the rendezvous binds it: pick another one, nothing else is retried
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), os.path.join(root, "tests", "_dp_worker.py"), out],
+                           capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     res = json.load(open(out))
     assert res["world"] == world and res["segments"] >= 3
@@ -653,9 +656,12 @@ def test_bench_two_ranks_rehearsal(dev):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {**os.environ, "MOFO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4"],
-                       capture_output=True, text=True, timeout=900, env=env)
+    for attempt in range(3):     # only a rendezvous port collision is retried (with another port)
+        r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4"],
+                           capture_output=True, text=True, timeout=900, env=env)
+        if r.returncode == 0 or "EADDRINUSE" not in r.stderr:
+            break
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
