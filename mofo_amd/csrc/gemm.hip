@@ -21,7 +21,8 @@
 // wave-instruction; bias / residual / pre-activation operands are read the same way.
 // GROUPED launches: up to MAXG problems of one (op, epilogue) kind in ONE grid (blockIdx -> problem by a prefix table);
 // the four weight-gradient GEMMs of a transformer block are issued together so that 108+36+144+144 tiles fill 256 CUs
-// without split-K (every split costs another f32 atomic pass over the gradient).
+// without split-K (every split costs another f32 atomic pass over the gradient); three encoder blocks' twelve together are
+// 1296 tiles = 5.06 per CU instead of 1.69 (tools/wgrad_group_exp.py: 89 -> 75 us per block's worth, 812 -> 963 TFLOP/s).
 #include "common.h"
 #include "../../include/mofo_hip.h"
 #include <stdlib.h>
@@ -51,7 +52,7 @@ struct GemmP {
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
 };
 
-constexpr int MAXG = 4;
+constexpr int MAXG = 12;   // three transformer blocks' four weight gradients in one launch (runtime.py: MOFO_WGRAD_BLOCKS)
 struct GroupP {
     GemmP p[MAXG];
     int start[MAXG + 1];   // first block of each problem; start[count] = grid size

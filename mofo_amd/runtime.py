@@ -306,6 +306,8 @@ class PretrainRuntime:
                     W.site = 2 * i
                 self._fp8_calibrated = False
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
+        # encoder blocks whose weight gradients share one grouped launch (1..3; mofo_gemm_grouped takes 12 problems)
+        self.wgrad_blocks = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS", "3"))))
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
@@ -359,21 +361,20 @@ class PretrainRuntime:
                   x_mid=e(M, D, dt=resid), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
                   x_out=e(M, D, dt=resid))
 
-    def _scratch(self, M, D, H, B, n):
+    def _scratch(self, M, D, H, B, n, group=1):
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        # the weight-gradient GEMMs of a block run on a side stream while the next blocks' activation-gradient chain
-        # proceeds, so everything they read (dh1, dx_mid copy, dqkv, dx_out copy) is double / triple buffered
+        ev = lambda: torch.cuda.Event() if self.dev.type == "cuda" else None
+        # the weight-gradient GEMMs of ``group`` consecutive blocks run as ONE launch on a side stream while the next blocks'
+        # activation-gradient chain proceeds, so everything they read (dh1, dx_mid copy, dqkv, the blocks' dx_out in the ring)
+        # lives in 2 * group scratch sets / 2 * group + 1 ring buffers: one group being read by its launch, one being written.
         # The residual-stream GRADIENT lives in bf16 only (ring / dxbB): each LayerNorm backward reads it as bf16 and writes
         # one bf16 tensor -- no f32 copy is written and re-read (the forward residual stream stays f32).
-        return NS(ring=[e(M, D), e(M, D), e(M, D)], dxln=e(M, D),
-                  sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(2)],
-                  dao=e(M, D), delta=e(B * H * n, dt=F32),
-                  ready=[torch.cuda.Event() for _ in range(2)] if self.dev.type == "cuda" else None,
-                  done=[torch.cuda.Event() for _ in range(2)] if self.dev.type == "cuda" else None, used=[False, False],
-                  att_ready=torch.cuda.Event() if self.dev.type == "cuda" else None,
-                  att_done=torch.cuda.Event() if self.dev.type == "cuda" else None)
+        return NS(group=group, ring=[e(M, D) for _ in range(2 * group + 1)], dxln=e(M, D),
+                  sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(2 * group)],
+                  dao=e(M, D), delta=e(B * H * n, dt=F32), pending=[], gidx=0, gcount=0,
+                  ready=[ev(), ev()], done=[ev(), ev()], used=[False, False], att_ready=ev(), att_done=ev())
 
     def ws(self, B: int, n_vis: Optional[int] = None, N: Optional[int] = None) -> NS:
         """workspace for batch size B (and visible-token count n_vis); allocated once, reused every step"""
@@ -400,7 +401,8 @@ class PretrainRuntime:
             w.enc = [self._block_ws(Me, d.enc_dim, d.enc_heads, B, n_vis) for _ in range(d.enc_depth)]
             w.enc_out = e(Me, d.enc_dim)
             w.enc_mean, w.enc_rstd = e(Me, dt=F32), e(Me, dt=F32)
-            w.enc_s = self._scratch(Me, d.enc_dim, d.enc_heads, B, n_vis)
+            # encoder: three blocks' weight gradients per launch (432 tiles of 128 x 128 per block = 1.69 per CU; 1296 = 5.06)
+            w.enc_s = self._scratch(Me, d.enc_dim, d.enc_heads, B, n_vis, group=self.wgrad_blocks)
             w.d_encout = e(Me, d.enc_dim)
         if self.dec_prefix is not None:
             Md = B * N
@@ -497,16 +499,23 @@ class PretrainRuntime:
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
 
-    def _block_bwd(self, W, L, S, k, x_in, dxb_out, dxb_in, B, n, H):
-        """dxb_out: gradient wrt the block output (bf16); writes dxb_in, which must NOT alias dxb_out.  ``k`` = parity of
-        the block: selects the scratch set whose buffers the block's deferred weight-gradient launch (side stream) reads
-        while the following block already runs."""
+    def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False):
+        """Backward of the j-th block of a backward pass (j = 0 for the top block).  Reads the gradient wrt the block output
+        from ``S.ring[j % R]`` (bf16), writes the gradient wrt its input to ``S.ring[(j + 1) % R]``.  The block's weight
+        gradients are DEFERRED: they join the pending group, which is launched on the side stream once it holds ``S.group``
+        blocks (or when ``flush`` says a gradient bucket ends here).  Scratch set j % (2 G) and ring buffer j % (2 G + 1) keep
+        what that launch reads while the following blocks already run: groups alternate between two event slots, a group
+        starts by waiting for the launch two groups back (launches are in order on the one side stream, and two consecutive
+        groups span at most 2 G blocks, so every buffer block j rewrites -- last used by block j - 2 G -- is free by then)."""
         scale = 64 ** -0.5
         D = x_in.shape[1]
-        T = S.sets[k]
-        side = self.side
-        if S.used[k]:   # the weight-gradient launch that last read this scratch set must be finished before it is rewritten
-            ops.host_op(lambda ev=S.done[k]: torch.cuda.current_stream().wait_event(ev))
+        G, R = S.group, len(S.ring)
+        T = S.sets[j % len(S.sets)]
+        dxb_out, dxb_in = S.ring[j % R], S.ring[(j + 1) % R]
+        slot = S.gidx % 2
+        if S.gcount == 0 and S.used[slot]:
+            ops.host_op(lambda ev=S.done[slot]: torch.cuda.current_stream().wait_event(ev))
+            S.used[slot] = False
         # MLP: x_out = x_mid + fc2(gelu(fc1(LN2(x_mid))))
         ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, dxb_out, W.fc2, T.dh1, aux=L.h1)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dh1, W.fc1, S.dxln)
@@ -546,19 +555,31 @@ class PretrainRuntime:
         self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
-        group = [(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
-                 (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
+        S.pending += [(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
+                      (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
+        S.gcount += 1
+        if S.gcount == G or flush:
+            self._wgrad_flush(S, slot, n)
+            S.gidx, S.gcount = S.gidx + 1, 0
+
+    def _wgrad_flush(self, S, slot, n):
+        """launch the pending blocks' weight gradients (one grouped launch) -- on the side stream unless MOFO_WGRAD_STREAM says
+        otherwise"""
+        if not S.pending:
+            return
+        group, S.pending = S.pending, []
         mode = os.environ.get("MOFO_WGRAD_STREAM", "side")
         if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
             self._wgrad_group(group)          # same stream: no fork / join events (each costs ~10 us of queue bubble)
             return
-        ops.host_op(lambda ev=S.ready[k]: ev.record(torch.cuda.current_stream()))
+        side = self.side
+        ops.host_op(lambda ev=S.ready[slot]: ev.record(torch.cuda.current_stream()))
         ops.use_stream(side)
-        ops.host_op(lambda ev=S.ready[k]: side.wait_event(ev))
+        ops.host_op(lambda ev=S.ready[slot]: side.wait_event(ev))
         self._wgrad_group(group)
-        ops.host_op(lambda ev=S.done[k]: ev.record(side))
+        ops.host_op(lambda ev=S.done[slot]: ev.record(side))
         ops.use_stream(None)
-        S.used[k] = True
+        S.used[slot] = True
 
     def _join_side(self, S):
         """main stream waits for every outstanding side-stream weight-gradient launch of this scratch"""
@@ -673,7 +694,7 @@ class PretrainRuntime:
     def encoder_backward(self, w: NS, d_out_bf16: torch.Tensor):
         d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
-        S.used = [False, False]
+        S.used, S.gidx, S.gcount = [False, False], 0, 0
         self._ln_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
                      s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
@@ -683,16 +704,20 @@ class PretrainRuntime:
         for nb in self._enc_buckets(d.enc_depth)[:-1]:
             i_end -= nb
             ends.add(i_end)
+        R = len(S.ring)
         for i in range(d.enc_depth - 1, -1, -1):
             x_in = w.enc[i - 1].x_out if i > 0 else w.enc_x0
-            self._block_bwd(self.encW[i], w.enc[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.n_vis, d.enc_heads)
+            # a gradient bucket's weight gradients must be complete when its range is handed to the all-reduce; without a
+            # bucket consumer (one process) the groups of three run on across the bucket boundaries
+            self._block_bwd(self.encW[i], w.enc[i], S, j, x_in, w.B, w.n_vis, d.enc_heads,
+                            flush=(i == 0 or (i in ends and self.segment_hook is not None)))
             j += 1
             if i in ends:
                 self._ln_flush()
                 self._join_side(S)
                 self._seg(seg)
                 seg += 1
-        self._wgrad(S.ring[j % 3], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
+        self._wgrad(S.ring[j % R], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
         self._ln_flush()
         self._join_side(S)
         self._seg(seg)
@@ -733,18 +758,18 @@ class PretrainRuntime:
         self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"))
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
-        S.used = [False, False]
+        S.used, S.gidx, S.gcount = [False, False], 0, 0
         ops.host_op(lambda: S.ring[0].zero_())
         self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
                      s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         j = 0
         for i in range(d.dec_depth - 1, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
-            self._block_bwd(self.decW[i], w.dec[i], S, j & 1, x_in, S.ring[j % 3], S.ring[(j + 1) % 3], w.B, w.N, d.dec_heads)
+            self._block_bwd(self.decW[i], w.dec[i], S, j, x_in, w.B, w.N, d.dec_heads, flush=(i == 0))
             j += 1
         self._ln_flush()
         self._join_side(S)
-        return S.ring[j % 3]       # gradient wrt the decoder input, bf16 [B*N, D]
+        return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
     # ------------------------------------------------------------------ whole model
     def _forward(self, w: NS):
@@ -790,7 +815,7 @@ class PretrainRuntime:
 
     def backward(self, w: NS):
         self.begin_backward()
-        self.cached(w, ("bwd", self._accumulate), lambda: self._backward(w))
+        self.cached(w, ("bwd", self._accumulate, self.segment_hook is not None), lambda: self._backward(w))
 
     # ------------------------------------------------------------------ optimizer side
     def grad_norm(self) -> torch.Tensor:
