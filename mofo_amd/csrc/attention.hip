@@ -326,13 +326,18 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 // Measured on the decoder shape (tools/attn_ab.py, one process): two-tile unrolling with compile-time buffer parity -4.9 %;
 // raised MFMA priority here +5 % (two waves per SIMD: the partner's VALU is what overlaps); -delta pre-loaded into the dP
 // accumulators instead of 16 subtractions +7 % (the dP chain then starts behind an LDS round trip); capped at 168 VGPRs for a
-// third wave per SIMD (216 needed): 30-48 spills, +21 % / 2.1x.
+// third wave per SIMD (216 needed): 30-48 spills, +21 % / 2.1x; a three-stage software pipeline inside each wave (S / dP of tile
+// t+1, the VALU of tile t and the dV / dK products of tile t-1 in one loop body, four LDS buffers, 244 VGPRs; LLVM first sank
+// the VALU behind the barrier, pinned with an asm use it did interleave ~6 VALU behind each MFMA): +3 %, bit-identical results.
+// What the phase stamps (tools/attn_trace.py dkv) show instead: of ~2 440 cycles per tile and wave, 730 go to writing the next
+// tile to LDS, the barrier and issuing the next global loads; the two 8-MFMA groups take 610 and 850 cycles (256 each alone).
 template <int NW, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int lddqkv) {
+                                                            bf16_t* __restrict__ dqkv, int lddqkv, int stagger) {
     constexpr bool PRELOAD = U2;
+    constexpr bool PRELOAD_C = U2;
     // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
     constexpr int BUF = 2 * TILE + 256;
     constexpr int NBUF = WHOLE ? 5 : 2;
@@ -394,6 +399,12 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     } else {
         gload(0);
         lwrite(0);
+        // Co-resident blocks start together and run the same phases at the same time (both in their MFMA phase, then both in
+        // their VALU phase).  A block whose wave 0 sits in an odd wave slot of its SIMD (HW_ID.wave_id) starts `stagger` x 64
+        // cycles late: -1.5 ... -3 % (tools/attn_ab.py --env MOFO_ATTN_STAGGER; any value from 5 to 30 gives the same).
+        if (stagger > 0 && wave == 0 && (__builtin_amdgcn_s_getreg(6148) & 1)) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        }
         __syncthreads();
         if (nqt > 1) gload(1);
     }
@@ -406,6 +417,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         const float* Dt = Lt + 32;
         f32x16 s = zero16(), dpv = zero16();
         f32x4 lvs[4];
+        ATTN_STAMP(qt, 0);
         if constexpr (PRELOAD) {
             // all eight row fragments in flight before the first MFMA: hipcc otherwise re-used one fragment register and
             // put a full LDS round trip (ds_read -> lgkmcnt(0)) in front of each of the 8 chained MFMAs
@@ -427,6 +439,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
         }
+        // the eight transposed fragments of the dV / dK products do not depend on the softmax: issued HERE, their LDS round trips
+        // pass under the exp2 / dS VALU block instead of in front of each of the eight MFMAs
+        ATTN_STAMP(qt, 1);
+        bf16x8 ot[4], qt4[4];
+        if constexpr (PRELOAD_C) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                ot[i] = tr_frag(Ot, i & 1, i >> 1, lane);
+                qt4[i] = tr_frag(Qt, i & 1, i >> 1, lane);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         float p[16], ds[16];
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
@@ -444,6 +468,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         }
         const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
         const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
+        ATTN_STAMP(qt, 2);
+        if constexpr (PRELOAD_C) {
+            // alternate the four accumulators: no MFMA waits for its predecessor's result
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot[0], pf0, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot[2], pf0, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt4[0], sf0, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt4[2], sf0, dk1, 0, 0, 0);
+            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot[1], pf1, dv0, 0, 0, 0);
+            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot[3], pf1, dv1, 0, 0, 0);
+            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt4[1], sf1, dk0, 0, 0, 0);
+            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt4[3], sf1, dk1, 0, 0, 0);
+        } else {
         dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 0, lane), pf0, dv0, 0, 0, 0);
         dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 0, lane), pf1, dv0, 0, 0, 0);
         dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 1, lane), pf0, dv1, 0, 0, 0);
@@ -452,11 +488,16 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
+        }
+        ATTN_STAMP(qt, 3);
         if constexpr (!WHOLE) {
             if (qt + 1 < nqt) lwrite(PAR >= 0 ? (PAR ^ 1) : ((qt + 1) & 1));
+            ATTN_STAMP(qt, 4);
             __syncthreads();
+            ATTN_STAMP(qt, 5);
             if (qt + 2 < nqt) gload(qt + 2);
         }
+        ATTN_STAMP(qt, 6);
     };
     using NoPar = std::integral_constant<int, -1>;
     if constexpr (U2 && !WHOLE) {
@@ -983,6 +1024,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // Forward softmax: a row's reference maximum moves only when a tile's maximum exceeds it by more than this many log2 units
 // (p <= 2^thr instead of <= 1; guide T13).  MOFO_ATTN_RESCALE_THR=0 restores the rescale-on-every-new-maximum form (tests
 // compare both); read per launch.
+// dK/dV pass: start delay (x 64 cycles) of the blocks in odd wave slots; MOFO_ATTN_STAGGER=0 turns it off (read per launch)
+int attn_stagger() {
+    const char* e = getenv("MOFO_ATTN_STAGGER");
+    return e ? atoi(e) : 10;
+}
 float rescale_thr() {
     const char* e = getenv("MOFO_ATTN_RESCALE_THR");
     return e ? (float)atof(e) : 6.0f;
@@ -1113,7 +1159,7 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
 #define LAUNCH_KV_(NW, WH, U2)                                                                                         \
     hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
-                       (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
+                       (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv, attn_stagger())
     switch (pick_nw(N)) {
         case 7: LAUNCH_KV(7); break;
         case 5: LAUNCH_KV(5); break;

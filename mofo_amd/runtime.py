@@ -308,6 +308,7 @@ class PretrainRuntime:
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         # encoder blocks whose weight gradients share one grouped launch (1..3; mofo_gemm_grouped takes 12 problems)
         self.wgrad_blocks = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS", "3"))))
+        self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
@@ -409,7 +410,7 @@ class PretrainRuntime:
             w.Md = Md
             w.x_full = e(B, N, d.dec_dim, dt=self.dec_resid)
             w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N, self.dec_resid) for _ in range(d.dec_depth)]
-            w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N)
+            w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self.wgrad_blocks_dec)
             if n_vis is not None:
                 Mm = B * (N - n_vis)
                 w.Mm = Mm
@@ -487,11 +488,12 @@ class PretrainRuntime:
         chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
         R = problems[0][0].shape[0]
         tiles = sum(((pr[0].shape[1] + 127) // 128) * ((pr[1].shape[1] + 127) // 128) for pr in problems)
-        # a group below `thr` tiles is split along the token reduction until it has ~`target` blocks: 756 = 3 resident blocks on
-        # each of 252 CUs (the decoder's 108 tiles x 7 splits; 4 splits / 432 blocks left most CUs with one or two blocks and
-        # their load -> MFMA latency chains uncovered: 242 -> 228 us per launch alone)
-        thr, target = int(os.environ.get("MOFO_WGRAD_THR", "200")), int(os.environ.get("MOFO_WGRAD_TARGET", "756"))
-        splits = 1 if tiles >= thr else int(max(1, min(-(-target // tiles), 16, R // 1024)))
+        # A group that leaves the 256 CUs with fewer than ~2.3 tiles each is split along the token reduction until it has
+        # ~`target` blocks (756 = 3 resident blocks on 252 CUs) -- but only while every split keeps >= 4096 token rows: each
+        # split adds a pass of f32 atomics over the gradients, which 64+ k-steps per tile amortise (decoder, 50 176 rows:
+        # 108 tiles x 7: 242 -> 228 us) and 40 do not (encoder, 5 120 rows: 2.28 -> 2.68 ms per step when split).
+        thr, target = int(os.environ.get("MOFO_WGRAD_THR", "600")), int(os.environ.get("MOFO_WGRAD_TARGET", "756"))
+        splits = 1 if tiles >= thr else int(max(1, min(-(-target // tiles), 16, R // 4096)))
         if splits == 1 and not self._accumulate and os.environ.get("MOFO_ZERO_ALL", "0") != "1":
             for pr in problems:                # plain stores: zero_grad may skip these tensors from now on
                 self.store.mark_overwritten(pr[2])

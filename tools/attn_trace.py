@@ -4,7 +4,7 @@
 Build first, in the container:  python tools/attn_trace.py --build   (attention.hip with -DMOFO_ATTN_TRACE)
 Stamps (wave 0 of every block, key tile 10): 0 tile start | 1 S = K Q^T MFMAs issued | 2 softmax / dS VALU done (operands
 packed) | 3 PV (or dQ) MFMAs issued | 4 next tile written to LDS | 5 barrier passed | 6 next-next tile's global loads issued.
-usage: attn_trace.py <fwd|dq|fused> B N H
+usage: attn_trace.py <fwd|dq|dkv|fused|onepass> B N H
 """
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ if "--build" in sys.argv:
     b.build()
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     obj = OUT + ".o"
-    subprocess.check_call([b.HIPCC] + b.FLAGS + ([] if os.environ.get("MOFO_TRACE_NOSTAMP") else ["-DMOFO_ATTN_TRACE"]) + os.environ.get("MOFO_TRACE_DEFS", "").split() + ["-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
+    subprocess.check_call([b.HIPCC] + b.FLAGS + b.EXTRA_FLAGS.get("attention.hip", []) + ([] if os.environ.get("MOFO_TRACE_NOSTAMP") else ["-DMOFO_ATTN_TRACE"]) + os.environ.get("MOFO_TRACE_DEFS", "").split() + ["-c", os.path.join(b.CSRC, "attention.hip"), "-o", obj])
     objs = [obj] + [os.path.join(b.HERE, "build", s + ".o") for s in b.SOURCES if s != "attention.hip"]
     subprocess.check_call([b.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs)
     print(OUT); sys.exit(0)
@@ -35,9 +35,13 @@ ops.attention_fwd(qkv, B, N, H, 0.125, out, lse)
 ops.attention_delta(out, dout, B, N, H, delta)
 f = {"fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse),
      "dq": lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
+     "dkv": lambda: ops.attention_bwd_dkv(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
      "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta),
      "onepass": lambda: ops.attention_bwd_onepass(qkv, dout, lse, delta, B, N, H, 0.125, dqkv)}[kind]
 names = ["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]
+if kind == "dkv":     # MOFO_ATTN_DKV_PIPE=0: the two-phase dK/dV kernel (query tile 10 of wave 0)
+    names = ["row-fragment reads + S, dP MFMAs issued (8)", "tr-fragment reads issued + exp2 / dS VALU + packs", "dV, dK MFMAs issued (8)",
+             "write next tile to LDS", "barrier", "issue next global loads"]
 if kind == "fused":   # N <= 160: the one-kernel backward
     names = ["issue loads + stage tiles + delta", "barrier", "step 0: pair (S, dP, dS, dV, dK)", "barrier", "step 0: dQ += K^T dS, barrier", "steps 1..T-1"]
 if kind == "onepass":   # N > 160: waves 0 and 4 (one SIMD's pair) of every block, query block 2, step 3
