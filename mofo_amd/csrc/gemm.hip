@@ -52,7 +52,7 @@ struct GemmP {
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
 };
 
-constexpr int MAXG = 12;   // three transformer blocks' four weight gradients in one launch (runtime.py: MOFO_WGRAD_BLOCKS)
+constexpr int MAXG = 13;   // three transformer blocks' four weight gradients + one more (patch embed / head) in one launch (runtime.py: MOFO_WGRAD_BLOCKS)
 struct GroupP {
     GemmP p[MAXG];
     int start[MAXG + 1];   // first block of each problem; start[count] = grid size

@@ -118,7 +118,7 @@ def gemm(op, epi, A, B, C_, **kw):
 
 
 def gemm_grouped(op, epi, problems):
-    """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 12)"""
+    """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 13)"""
     built = [_gemm_args(op, epi, A, B, C_, **kw) for A, B, C_, kw in problems]
     arr = (GemmArgs * len(built))(*[b[0] for b in built])
     _run("mofo_gemm_grouped", ("gemm", op, epi), (sum(b[1] for b in built), sum(b[2] for b in built)), arr, len(built))

@@ -125,6 +125,7 @@ class FlatStore:
                 p.data = v
         self.attach_grads()
         self._skip_zero = np.zeros(self.total // CHUNK, dtype=bool)   # chunks the backward overwrites (mark_overwritten)
+        self._must_zero = np.zeros(self.total // CHUNK, dtype=bool)   # chunks some recorded backward adds to (mark_accumulated)
         self._zero_list = None
         self._shadow_version = -1
         self.shadow_epoch = 0      # bumped whenever the bf16 shadow changes (the e4m3 shadow follows it)
@@ -233,14 +234,26 @@ class FlatStore:
             self._skip_zero[lo:hi] = True
             self._zero_list = None
 
+    def mark_accumulated(self, g: torch.Tensor):
+        """``g`` is ADDED to by some recorded backward (a split weight-gradient GEMM: f32 atomics): zero_grads() must clear it,
+        whatever another workspace's backward marked (a small batch runs the same GEMM unsplit and overwrites)"""
+        o = (g.data_ptr() - self.grads.data_ptr()) // 4
+        lo, hi = o // CHUNK, -(-(o + g.numel()) // CHUNK)          # every chunk the tensor touches
+        stale = bool((self._skip_zero[lo:hi] & ~self._must_zero[lo:hi]).any())   # the zero_grads() before this call skipped it
+        if not bool(self._must_zero[lo:hi].all()):
+            self._must_zero[lo:hi] = True
+            self._zero_list = None
+        return stale
+
     def zero_grads(self):
         """optimizer.zero_grad(): everything the next backward accumulates into is cleared; the weight gradients it overwrites
         with plain stores (the encoder blocks' at ViT-B: 340 of 377 MB) are left as they are until that backward rewrites them"""
-        if not self._skip_zero.any():
+        skip = self._skip_zero & ~self._must_zero
+        if not skip.any():
             self.grads.zero_()
         else:
             if self._zero_list is None:
-                self._zero_list = torch.from_numpy(np.nonzero(~self._skip_zero)[0].astype(np.int32)).to(self.device)
+                self._zero_list = torch.from_numpy(np.nonzero(~skip)[0].astype(np.int32)).to(self.device)
             ops.zero_chunks(self.grads, self._zero_list)
         self.fresh = True    # the next backward may overwrite (plain stores) instead of accumulate
 
@@ -497,11 +510,15 @@ class PretrainRuntime:
         if splits == 1 and not self._accumulate and os.environ.get("MOFO_ZERO_ALL", "0") != "1":
             for pr in problems:                # plain stores: zero_grad may skip these tensors from now on
                 self.store.mark_overwritten(pr[2])
+        elif splits > 1:
+            for pr in problems:                # f32 atomics onto what zero_grad left there
+                if self.store.mark_accumulated(pr[2]) and not self._accumulate:
+                    pr[2].zero_()              # (recording run only) another workspace's backward had made zero_grads skip it
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
 
-    def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False):
+    def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False, hold=False):
         """Backward of the j-th block of a backward pass (j = 0 for the top block).  Reads the gradient wrt the block output
         from ``S.ring[j % R]`` (bf16), writes the gradient wrt its input to ``S.ring[(j + 1) % R]``.  The block's weight
         gradients are DEFERRED: they join the pending group, which is launched on the side stream once it holds ``S.group``
@@ -560,7 +577,7 @@ class PretrainRuntime:
         S.pending += [(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
                       (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
         S.gcount += 1
-        if S.gcount == G or flush:
+        if (S.gcount == G or flush) and not hold:      # hold: the caller adds one more problem to this group and flushes it
             self._wgrad_flush(S, slot, n)
             S.gidx, S.gcount = S.gidx + 1, 0
 
@@ -712,14 +729,17 @@ class PretrainRuntime:
             # a gradient bucket's weight gradients must be complete when its range is handed to the all-reduce; without a
             # bucket consumer (one process) the groups of three run on across the bucket boundaries
             self._block_bwd(self.encW[i], w.enc[i], S, j, x_in, w.B, w.n_vis, d.enc_heads,
-                            flush=(i == 0 or (i in ends and self.segment_hook is not None)))
+                            flush=(i in ends and self.segment_hook is not None), hold=(i == 0))
             j += 1
             if i in ends:
                 self._ln_flush()
                 self._join_side(S)
                 self._seg(seg)
                 seg += 1
-        self._wgrad(S.ring[j % R], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"))
+        # the patch-embed weight gradient (72 tiles alone) rides in the last blocks' grouped launch
+        S.pending.append((S.ring[j % R], w.xp, s.g2d(p + "patch_embed.proj.weight"), s.gview(p + "patch_embed.proj.bias"), (0, 0)))
+        self._wgrad_flush(S, S.gidx % 2, w.n_vis)
+        S.gidx, S.gcount = S.gidx + 1, 0
         self._ln_flush()
         self._join_side(S)
         self._seg(seg)
@@ -757,10 +777,11 @@ class PretrainRuntime:
     def decoder_backward(self, w: NS, dpred_bf16: torch.Tensor, x_full: torch.Tensor, n_ret: int):
         d, s, p, S = self.d, self.store, self.dec_prefix, w.dec_s
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, dpred_bf16, s.bview(p + "head.weight"), w.d_decln)
-        self._wgrad(dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"))
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
-        # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
         S.used, S.gidx, S.gcount = [False, False], 0, 0
+        # the head's weight gradient (36 tiles) joins the first decoder block's grouped launch on the side stream
+        S.pending.append((dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"), (0, 0)))
+        # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
         ops.host_op(lambda: S.ring[0].zero_())
         self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
                      s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
@@ -769,6 +790,8 @@ class PretrainRuntime:
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
             self._block_bwd(self.decW[i], w.dec[i], S, j, x_in, w.B, w.N, d.dec_heads, flush=(i == 0))
             j += 1
+        if S.pending:                      # a decoder without blocks: the head's weight gradient alone
+            self._wgrad_flush(S, S.gidx % 2, w.N)
         self._ln_flush()
         self._join_side(S)
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]

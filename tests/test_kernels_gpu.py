@@ -254,8 +254,23 @@ def test_gemm_grouped_wgrad(dev):
     ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs2)
     for (dY, X, G, _), ref in zip(probs2, refs):
         assert _rel(G, 2 * ref) < 1e-5
+    # thirteen problems in one launch (three blocks' four weight gradients + one more, as the runtime groups them), with
+    # different reduction lengths inside one group
+    big, bigrefs = [], []
+    for rep in range(3):
+        for i, (P, Q) in enumerate(shapes):
+            Rr = R - 64 * rep
+            dY, X = _rand((Rr, P), dev, 30 + 4 * rep + i), _rand((Rr, Q), dev, 50 + 4 * rep + i)
+            big.append((dY, X, torch.full((P, Q), float("nan"), dtype=F32, device=dev), dict(splits=1, accumulate=False)))
+            bigrefs.append(dY.float().t() @ X.float())
+    dY, X = _rand((R, 384), dev, 70), _rand((R, 1536), dev, 71)
+    big.append((dY, X, torch.full((384, 1536), float("nan"), dtype=F32, device=dev), dict(splits=1, accumulate=False)))
+    bigrefs.append(dY.float().t() @ X.float())
+    ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, big)
+    for (dY, X, G, _), ref in zip(big, bigrefs):
+        assert _rel(G, ref) < 1e-5
     with pytest.raises(RuntimeError, match="count"):
-        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs + probs[:1])
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, big + probs[:1])
 
 
 def test_gemm_rejects_bad_shapes(dev):
