@@ -246,7 +246,7 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_kernel(const float* __res
 // The same for up to FIN_MAX LayerNorms in ONE launch: the per-LayerNorm launch cost 6 us x 34 per step for 0.1 us of work;
 // the runtime now lets a gradient bucket's LayerNorms leave their block partials in separate workspaces and reduces them
 // together before the bucket's all-reduce / the optimizer needs them.
-constexpr int FIN_MAX = 8;
+constexpr int FIN_MAX = 40;   // one launch for all 34 LayerNorms of a ViT-B step when nothing consumes gradient buckets earlier
 struct FinItems {
     const float* partial[FIN_MAX];
     float* dw[FIN_MAX];

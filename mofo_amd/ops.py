@@ -317,11 +317,11 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
 
 
 def layernorm_bwd_finalize(items):
-    """items = [(partial_ws, nblocks, D, dw, db), ...] (at most 8) left behind by deferred layernorm_bwd calls: one launch
+    """items = [(partial_ws, nblocks, D, dw, db), ...] (at most 40) left behind by deferred layernorm_bwd calls: one launch
     adds every LayerNorm's block partials to its dw / db"""
     n = len(items)
-    if not 1 <= n <= 8:
-        raise ValueError("layernorm_bwd_finalize: 1..8 items")
+    if not 1 <= n <= 40:
+        raise ValueError("layernorm_bwd_finalize: 1..40 items")
     for ws, nb, D, dw, db in items:
         _chk(ws, F32, "partial_ws", 1), _chk(dw, F32, "dw", 1), _chk(db, F32, "db", 1)
         if dw.numel() != D or db.numel() != D or ws.numel() < 2 * nb * D or not 1 <= nb <= 1024:

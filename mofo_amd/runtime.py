@@ -333,8 +333,8 @@ class PretrainRuntime:
     # ------------------------------------------------------------------ LayerNorm backward with grouped dgamma / dbeta reduction
     def _ln_bwd(self, dy, x, w, mean, rstd, dres, dx, dxb, gw, gb, **kw):
         """ops.layernorm_bwd whose dgamma / dbeta block partials stay in a workspace of their own; ``_ln_flush`` reduces up
-        to eight LayerNorms' partials in one launch (before a gradient bucket is handed to the all-reduce / optimizer)"""
-        if len(self._ln_pending) == 8:
+        to forty LayerNorms' partials in one launch (before a gradient bucket is handed to the all-reduce / optimizer)"""
+        if len(self._ln_pending) == 40:
             self._ln_flush()
         D = x.shape[1]
         k = len(self._ln_pending)
@@ -732,8 +732,9 @@ class PretrainRuntime:
                             flush=(i in ends and self.segment_hook is not None), hold=(i == 0))
             j += 1
             if i in ends:
-                self._ln_flush()
-                self._join_side(S)
+                if self.segment_hook is not None:      # a bucket consumer needs the range complete here; otherwise the LayerNorm
+                    self._ln_flush()                   # partials wait for the ONE reduce launch at the end of the backward
+                    self._join_side(S)
                 self._seg(seg)
                 seg += 1
         # the patch-embed weight gradient (72 tiles alone) rides in the last blocks' grouped launch
@@ -774,7 +775,7 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, w.dec_ln, s.bview(p + "head.weight"), w.pred, bias=s.view(p + "head.bias"))
         return w.pred
 
-    def decoder_backward(self, w: NS, dpred_bf16: torch.Tensor, x_full: torch.Tensor, n_ret: int):
+    def decoder_backward(self, w: NS, dpred_bf16: torch.Tensor, x_full: torch.Tensor, n_ret: int, defer_ln: bool = False):
         d, s, p, S = self.d, self.store, self.dec_prefix, w.dec_s
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, dpred_bf16, s.bview(p + "head.weight"), w.d_decln)
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
@@ -792,7 +793,8 @@ class PretrainRuntime:
             j += 1
         if S.pending:                      # a decoder without blocks: the head's weight gradient alone
             self._wgrad_flush(S, S.gidx % 2, w.N)
-        self._ln_flush()
+        if not defer_ln:                   # defer_ln: the caller runs the encoder backward next and reduces all LayerNorms at its end
+            self._ln_flush()
         self._join_side(S)
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
@@ -827,7 +829,7 @@ class PretrainRuntime:
                            lambda: self._loss_forward(w, normalize_target, grad_scale))
 
     def _backward(self, w: NS):
-        dx_full = self.decoder_backward(w, w.dpred, w.x_full, w.n_msk)
+        dx_full = self.decoder_backward(w, w.dpred, w.x_full, w.n_msk, defer_ln=self.segment_hook is None)
         d_encout = self.bridge_backward(w, dx_full, w.enc_out)
         self._seg(0)
         self.encoder_backward(w, d_encout)

@@ -398,7 +398,7 @@ def test_layernorm_bwd_deferred_grouped_finalize(dev):
     for (_, _, _, dw, db), (rw, rb) in zip(items, want):
         assert torch.allclose(dw, rw, rtol=1e-5, atol=1e-5) and torch.allclose(db, rb, rtol=1e-5, atol=1e-5)
     with pytest.raises(ValueError):
-        ops.layernorm_bwd_finalize(items * 3)
+        ops.layernorm_bwd_finalize(items * 14)     # more than 40 items
 
 
 def test_layernorm_rowmap(dev):
