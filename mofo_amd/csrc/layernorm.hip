@@ -93,6 +93,81 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
     }
 }
 
+// bf16 input with D <= 512 (the decoder's stream): one 16-B load per lane and row, TWO rows per wave in flight (the general
+// kernel's 8-B loads and one row per wave left ~24 KB in flight per CU: 3.3 TB/s on the 77 MB of a decoder LayerNorm).
+__global__ __launch_bounds__(256) void ln_fwd_bf16_2row_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float eps, int M, int D, int rows_in,
+                                                                int rows_out, int row_off, bf16_t* __restrict__ y, int ldy,
+                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r0 = (blockIdx.x * 4 + wave) * 2;
+    if (r0 >= M) return;
+    const int c = lane * 8;
+    const bool on = c < D;
+    float v[2][8];
+    float s[2] = {0.f, 0.f};
+    int rr[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        rr[k] = r0 + k < M ? r0 + k : r0;
+        u32x4 t = {0u, 0u, 0u, 0u};
+        if (on) t = *(const u32x4*)(x + map_row(rr[k], rows_in, rows_out, row_off) * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[k][2 * e] = bf16lo_to_f32(t[e]);
+            v[k][2 * e + 1] = bf16hi_to_f32(t[e]);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[k] += v[k][e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s[0] += __shfl_xor(s[0], o, 64);
+        s[1] += __shfl_xor(s[1], o, 64);
+    }
+    const float mu[2] = {s[0] / D, s[1] / D};
+    float q[2] = {0.f, 0.f};
+    if (on) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float d = v[k][e] - mu[k];
+                q[k] += d * d;
+            }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        q[0] += __shfl_xor(q[0], o, 64);
+        q[1] += __shfl_xor(q[1], o, 64);
+    }
+    const float rs[2] = {rsqrtf(q[0] / D + eps), rsqrtf(q[1] / D + eps)};
+    f32x4 w0 = {0.f, 0.f, 0.f, 0.f}, w1 = w0, b0 = w0, b1 = w0;
+    if (on) {
+        w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
+        b0 = *(const f32x4*)(b + c), b1 = *(const f32x4*)(b + c + 4);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && r0 + 1 >= M) break;
+        if (lane == 0) {
+            mean[rr[k]] = mu[k];
+            rstd[rr[k]] = rs[k];
+        }
+        if (on) {
+            float o[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o[e] = (v[k][e] - mu[k]) * rs[k] * w0[e] + b0[e];
+                o[4 + e] = (v[k][4 + e] - mu[k]) * rs[k] * w1[e] + b1[e];
+            }
+            *(u32x4*)(y + (size_t)rr[k] * ldy + c) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+        }
+    }
+}
+
 // Two rows per wave per iteration: both rows' loads are issued before either row's shuffle reductions, so the HBM
 // latency of one row hides behind the arithmetic of the other (the one-row form ran at 2-2.8 TB/s in the step).
 template <int NIT, bool XB>
@@ -333,6 +408,12 @@ extern "C" int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const f
     if (ldx % 4 || ldy % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_fwd: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
+    if (x_is_bf16 && D % 8 == 0 && D <= 512 && ldx % 8 == 0 && ldy % 8 == 0) {
+        hipLaunchKernelGGL(ln_fwd_bf16_2row_kernel, dim3(ceil_div(M, 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, eps, M, D, rows_in, rows_out,
+                           row_off, (bf16_t*)y, ldy, mean, rstd);
+        MOFO_CHECK_LAUNCH("mofo_layernorm_fwd");
+        return MOFO_OK;
+    }
     dim3 grid(ceil_div(M, 4)), block(256);
 #define GO(N_) do { if (x_is_bf16) hipLaunchKernelGGL((ln_fwd_kernel<N_, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd); \
                     else hipLaunchKernelGGL((ln_fwd_kernel<N_, false>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd); } while (0)

@@ -793,9 +793,9 @@ class PretrainRuntime:
             j += 1
         if S.pending:                      # a decoder without blocks: the head's weight gradient alone
             self._wgrad_flush(S, S.gidx % 2, w.N)
-        if not defer_ln:                   # defer_ln: the caller runs the encoder backward next and reduces all LayerNorms at its end
-            self._ln_flush()
-        self._join_side(S)
+        if not defer_ln:                   # defer_ln: the caller runs the encoder backward next; its final LayerNorm reduce and its
+            self._ln_flush()               # join of the (one, in-order) side stream cover this pass's launches as well
+            self._join_side(S)
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
     # ------------------------------------------------------------------ whole model
