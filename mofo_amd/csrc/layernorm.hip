@@ -340,8 +340,18 @@ __global__ __launch_bounds__(256) void ln_bwd_finalize_grouped_kernel(FinItems i
     const int per = (nblocks + FIN_SLICES - 1) / FIN_SLICES;
     const int b0 = slice * per, b1 = min(nblocks, b0 + per);
     float s = 0.f;
-    if (c < D)
-        for (int b = b0 + part; b < b1; b += 4) s += partial[((size_t)b * 2 + which) * D + c];
+    if (c < D) {
+        // eight independent loads in flight per thread (the one-load-per-iteration loop read 126 MB of partials at 1.5 TB/s: 84 us
+        // on the critical path in front of AdamW)
+        float a[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int b = b0 + part;
+        for (; b + 28 < b1; b += 32) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a[u] += partial[((size_t)(b + 4 * u) * 2 + which) * D + c];
+        }
+        for (; b < b1; b += 4) a[0] += partial[((size_t)b * 2 + which) * D + c];
+        s = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    }
     red[part][cl] = s;
     __syncthreads();
     if (part == 0 && c < D && b0 < b1) atomicAdd((which ? it.db[item] : it.dw[item]) + c, red[0][cl] + red[1][cl] + red[2][cl] + red[3][cl]);
