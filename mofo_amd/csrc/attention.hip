@@ -329,7 +329,14 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 // third wave per SIMD (216 needed): 30-48 spills, +21 % / 2.1x; a three-stage software pipeline inside each wave (S / dP of tile
 // t+1, the VALU of tile t and the dV / dK products of tile t-1 in one loop body, four LDS buffers, 244 VGPRs; LLVM first sank
 // the VALU behind the barrier, pinned with an asm use it did interleave ~6 VALU behind each MFMA): +3 %, bit-identical results.
-// What the phase stamps (tools/attn_trace.py dkv) show instead: of ~2 440 cycles per tile and wave, 730 go to writing the next
+// ABLATION (variant builds, one process): without staging + barrier -17 %, without the exp2 / dS arithmetic -8 %, without both the
+// kernel still takes 75 % of its time: the core is "one freshly read 1-KiB LDS fragment per MFMA" at two waves per SIMD.  A
+// 64-keys-per-wave form was built to halve that (each Q / dO fragment feeds two MFMAs; dK / dV of 64 keys in 128 AccVGPRs and the
+// K / V fragments in 64 more through inline-asm MFMAs, one wave per SIMD; the VALU of one key tile fenced chunk by chunk between
+// the MFMAs of the other through dummy asm operands; bit-identical results): 279 vs 266 us (profiles/r02_attn_fat_wave.txt).  With
+// one wave per SIMD only ~4 VALU hide behind an MFMA (tools/micro/coissue_probe.hip) and 10 sit in each of 16 gaps; spreading them
+// over all 32 gaps needs the S / dP accumulators double-buffered across query tiles, which no longer fits 256 arch VGPRs.  Removed.
+// What the phase stamps (tools/attn_trace.py dkv) show: of ~2 440 cycles per tile and wave, 730 go to writing the next
 // tile to LDS, the barrier and issuing the next global loads; the two 8-MFMA groups take 610 and 850 cycles (256 each alone).
 template <int NW, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
