@@ -163,7 +163,7 @@ def main():
             w_, h_ = np.random.randint(32, 161, 2)
             masks.append(bgen(np.tile(np.array([x1, y1, min(224, x1 + w_), min(224, y1 + h_)]), (16, 1))))
     mask_u8.copy_(torch.from_numpy(np.stack(masks).astype(np.uint8)))
-    mask_dev = mask_u8.clone()
+    mask_dev = mask_u8            # resident in the model's input buffer, like the clips (no per-step staging copy)
     _Args.lr = 1.5e-4 * (B * world) / 256                          # run_mae_pretraining.py:217
     opt = optim_factory.create_optimizer(_Args, model)
     wrapped = DataParallel(model) if (world > 1 or force_dp) else model

@@ -458,7 +458,8 @@ class PretrainRuntime:
             if videos.data_ptr() != w.clips.data_ptr():
                 w.clips.copy_(videos, non_blocking=True)
         if mask is not None:
-            w.mask_u8.copy_(mask.reshape(w.B, -1), non_blocking=True)
+            if mask.data_ptr() != w.mask_u8.data_ptr():       # a loader may write masks straight into the persistent buffer, like clips
+                w.mask_u8.copy_(mask.reshape(w.B, -1), non_blocking=True)
             ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
 
     # ------------------------------------------------------------------ transformer block
