@@ -345,9 +345,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
                                                             bf16_t* __restrict__ dqkv, int lddqkv, int stagger) {
     constexpr bool PRELOAD = U2;
     constexpr bool PRELOAD_C = U2;
+    constexpr bool PAIR = U2 && !WHOLE;    // two query tiles staged per barrier (four LDS tile buffers): -2 %
     // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
     constexpr int BUF = 2 * TILE + 256;
-    constexpr int NBUF = WHOLE ? 5 : 2;
+    constexpr int NBUF = WHOLE ? 5 : (PAIR ? 4 : 2);
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * BUF];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     int xb, b, h;
@@ -373,29 +374,39 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
     const int nqt = (N + 31) >> 5;
-    u32x4 qreg = {0, 0, 0, 0}, oreg = {0, 0, 0, 0};
-    float sreg = 0.f;
-    auto gload = [&](int qt) {
+    u32x4 qreg = {0, 0, 0, 0}, oreg = {0, 0, 0, 0}, qreg2 = {0, 0, 0, 0}, oreg2 = {0, 0, 0, 0};
+    float sreg = 0.f, sreg2 = 0.f;
+    auto gload_to = [&](int qt, u32x4& qr, u32x4& orr, float& sr) {
         if (tid < 256) {
             int r = qt * 32 + (tid >> 3);
             r = r < N ? r : N - 1;
-            qreg = *(const u32x4*)(qp + (size_t)r * ldqkv + (tid & 7) * 8);
-            oreg = *(const u32x4*)(dop + (size_t)r * lddo + (tid & 7) * 8);
+            qr = *(const u32x4*)(qp + (size_t)r * ldqkv + (tid & 7) * 8);
+            orr = *(const u32x4*)(dop + (size_t)r * lddo + (tid & 7) * 8);
             if (tid < 64) {
                 const int qq = qt * 32 + (tid & 31);
                 // a query row beyond N must contribute nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
-                if (tid < 32) sreg = qq < N ? lp[qq] : 1.0e30f;
-                else sreg = qq < N ? dp_[qq] : 0.f;
+                if (tid < 32) sr = qq < N ? lp[qq] : 1.0e30f;
+                else sr = qq < N ? dp_[qq] : 0.f;
             }
         }
     };
-    auto lwrite = [&](int buf) {
+    auto lwrite_from = [&](int buf, const u32x4& qr, const u32x4& orr, float sr) {
         if (tid < 256) {
             unsigned char* d = smem + buf * BUF + (tid >> 3) * RS + (((tid & 7) ^ swz(tid >> 3)) << 4);
-            *(u32x4*)d = qreg;
-            *(u32x4*)(d + TILE) = oreg;
-            if (tid < 64) *(float*)(smem + buf * BUF + 2 * TILE + tid * 4) = sreg;
+            *(u32x4*)d = qr;
+            *(u32x4*)(d + TILE) = orr;
+            if (tid < 64) *(float*)(smem + buf * BUF + 2 * TILE + tid * 4) = sr;
         }
+    };
+    auto gload = [&](int qt) { gload_to(qt, qreg, oreg, sreg); };
+    auto lwrite = [&](int buf) { lwrite_from(buf, qreg, oreg, sreg); };
+    auto gload2 = [&](int pr) {            // both query tiles of pair pr (a tile beyond the sequence re-reads clamped rows)
+        gload_to(2 * pr, qreg, oreg, sreg);
+        gload_to(2 * pr + 1, qreg2, oreg2, sreg2);
+    };
+    auto lwrite2 = [&](int pb) {           // pair buffer pb = tile buffers 2 pb, 2 pb + 1
+        lwrite_from(2 * pb, qreg, oreg, sreg);
+        lwrite_from(2 * pb + 1, qreg2, oreg2, sreg2);
     };
     if constexpr (WHOLE) {
         for (int qt = 0; qt < nqt; ++qt) {
@@ -403,6 +414,14 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             lwrite(qt);
         }
         __syncthreads();
+    } else if constexpr (PAIR) {
+        gload2(0);
+        lwrite2(0);
+        if (stagger > 0 && wave == 0 && (__builtin_amdgcn_s_getreg(6148) & 1)) {
+            for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+        if (nqt > 2) gload2(1);
     } else {
         gload(0);
         lwrite(0);
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
 
     auto qtile = [&](int qt, auto parity_tag) {
         constexpr int PAR = decltype(parity_tag)::value;       // -1: buffer parity from qt at run time
-        const unsigned char* Qt = smem + (WHOLE ? qt : (PAR >= 0 ? PAR : (qt & 1))) * BUF;
+        const unsigned char* Qt = smem + (WHOLE ? qt : (PAR >= 0 ? PAR : (PAIR ? (qt & 3) : (qt & 1)))) * BUF;
         const unsigned char* Ot = Qt + TILE;
         const float* Lt = (const float*)(Qt + 2 * TILE);
         const float* Dt = Lt + 32;
@@ -497,7 +516,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
         }
         ATTN_STAMP(qt, 3);
-        if constexpr (!WHOLE) {
+        if constexpr (!WHOLE && !PAIR) {
             if (qt + 1 < nqt) lwrite(PAR >= 0 ? (PAR ^ 1) : ((qt + 1) & 1));
             ATTN_STAMP(qt, 4);
             __syncthreads();
@@ -507,7 +526,25 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         ATTN_STAMP(qt, 6);
     };
     using NoPar = std::integral_constant<int, -1>;
-    if constexpr (U2 && !WHOLE) {
+    if constexpr (PAIR) {
+        // one barrier and one staging round per TWO query tiles: pair pr computes from pair buffer pr & 1 while the next pair's
+        // global loads are in flight; they are written to the other pair buffer behind the pair's last MFMAs
+        const int npair = (nqt + 1) >> 1;
+        auto pair = [&](int pr, auto pb_tag) {
+            constexpr int PB = decltype(pb_tag)::value;
+            qtile(2 * pr, std::integral_constant<int, 2 * PB>{});
+            if (2 * pr + 1 < nqt) qtile(2 * pr + 1, std::integral_constant<int, 2 * PB + 1>{});
+            if (pr + 1 < npair) lwrite2(PB ^ 1);
+            __syncthreads();
+            if (pr + 2 < npair) gload2(pr + 2);
+        };
+        int pr = 0;
+        for (; pr + 1 < npair; pr += 2) {
+            pair(pr, std::integral_constant<int, 0>{});
+            pair(pr + 1, std::integral_constant<int, 1>{});
+        }
+        if (pr < npair) pair(pr, std::integral_constant<int, 0>{});
+    } else if constexpr (U2 && !WHOLE) {
         int qt = 0;
         for (; qt + 1 < nqt; qt += 2) {
             qtile(qt, std::integral_constant<int, 0>{});
