@@ -24,6 +24,8 @@ import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL's peer mappings (multi-process runs)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts (see mofo_amd/__init__.py)
+
 import numpy as np
 import torch
 

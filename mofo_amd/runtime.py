@@ -324,6 +324,7 @@ class PretrainRuntime:
         self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
+        self._seg_events = [torch.cuda.Event() for _ in range(8)] if self.dev.type == "cuda" else []
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)
         self.ln_ws = torch.empty(2 * 1024 * dmax, dtype=F32, device=self.dev)   # LN-backward dgamma/dbeta block partials
@@ -654,8 +655,21 @@ class PretrainRuntime:
         ops.host_op(lambda: self._seg_now(idx))
 
     def _seg_now(self, idx: int):
-        if self.segment_hook is not None:
-            lo, hi = self.segments[idx]
+        if self.segment_hook is None:
+            return
+        lo, hi = self.segments[idx]
+        if self.side is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+            self.segment_hook(idx, lo, hi)
+            return
+        # The range's kernels were issued on TWO streams (activation-gradient chain + LayerNorm reduces on the caller's, grouped
+        # weight gradients on the side stream) and the consumer (torch.distributed's all-reduce) orders itself behind torch's
+        # CURRENT stream: it is handed the range on the side stream, which first waits for an event recorded here on the main
+        # stream.  The exchange starts behind both, and the main stream never joins a weight-gradient launch at a bucket end
+        # (that join cost the data-parallel step 0.27 ms; MOFO_SEG_HANDOFF=0 restores it).
+        ev = self._seg_events[idx % len(self._seg_events)]
+        ev.record(torch.cuda.current_stream())
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
             self.segment_hook(idx, lo, hi)
 
     def cached(self, w: NS, tag, fn):
@@ -735,7 +749,8 @@ class PretrainRuntime:
             if i in ends:
                 if self.segment_hook is not None:      # a bucket consumer needs the range complete here; otherwise the LayerNorm
                     self._ln_flush()                   # partials wait for the ONE reduce launch at the end of the backward
-                    self._join_side(S)
+                    if os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+                        self._join_side(S)
                 self._seg(seg)
                 seg += 1
         # the patch-embed weight gradient (72 tiles alone) rides in the last blocks' grouped launch
@@ -796,7 +811,8 @@ class PretrainRuntime:
             self._wgrad_flush(S, S.gidx % 2, w.N)
         if not defer_ln:                   # defer_ln: the caller runs the encoder backward next; its final LayerNorm reduce and its
             self._ln_flush()               # join of the (one, in-order) side stream cover this pass's launches as well
-            self._join_side(S)
+            if self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+                self._join_side(S)
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
     # ------------------------------------------------------------------ whole model
