@@ -296,6 +296,9 @@ class PretrainRuntime:
         # per ViT-B B=32 step).  The encoder's stream (5 120 token rows, latency-bound kernels) stays f32.  MOFO_DEC_RESID=f32
         # restores the f32 decoder stream (A/B, parity debugging).
         self.dec_resid = F32 if os.environ.get("MOFO_DEC_RESID", "bf16") == "f32" else BF16
+        # MOFO_ENC_RESID=bf16: the same for the encoder -- parity gates pass, the step does not move (11.90 / 11.92 vs 11.96 / 11.87 ms:
+        # its kernels are latency-bound at 5 120 token rows), so the reference's f32 stream stays the default there
+        self.enc_resid = BF16 if os.environ.get("MOFO_ENC_RESID", "f32") == "bf16" else F32
         # MOFO_FP8=1: the forward Linears fed by a LayerNorm (qkv, fc1) run on OCP e4m3 operands with the block-scaled MFMA
         # (2x the bf16 MFMA rate; BASELINE configs[4] "fp8 MFMA attention/MLP").  Per-tensor scales: weights from their amax
         # every time the shadow changes, activations with delayed scaling (a LayerNorm's scale comes from the amax it saw in
@@ -412,8 +415,8 @@ class PretrainRuntime:
             Me = B * n_vis
             w.Me = Me
             w.xp = e(Me, d.patch_dim)
-            w.enc_x0 = e(Me, d.enc_dim, dt=F32)
-            w.enc = [self._block_ws(Me, d.enc_dim, d.enc_heads, B, n_vis) for _ in range(d.enc_depth)]
+            w.enc_x0 = e(Me, d.enc_dim, dt=self.enc_resid)
+            w.enc = [self._block_ws(Me, d.enc_dim, d.enc_heads, B, n_vis, self.enc_resid) for _ in range(d.enc_depth)]
             w.enc_out = e(Me, d.enc_dim)
             w.enc_mean, w.enc_rstd = e(Me, dt=F32), e(Me, dt=F32)
             # encoder: three blocks' weight gradients per launch (432 tiles of 128 x 128 per block = 1.69 per CU; 1296 = 5.06)
@@ -717,7 +720,7 @@ class PretrainRuntime:
             ops.patch_gather_u8(w.frames_u8, d.tubelet, d.patch_size, w.vis_idx, w.xp)
         else:
             ops.patch_gather(w.clips, d.tubelet, d.patch_size, w.vis_idx, w.xp)
-        ops.gemm(ops.GEMM_NT, ops.EPI_POS_F32, w.xp, s.bview(p + "patch_embed.proj.weight"), w.enc_x0,
+        ops.gemm(ops.GEMM_NT, ops.EPI_POS_BF16 if w.enc_x0.dtype == BF16 else ops.EPI_POS_F32, w.xp, s.bview(p + "patch_embed.proj.weight"), w.enc_x0,
                  bias=s.view(p + "patch_embed.proj.bias"), pos=self.pos_enc, row_idx=w.vis_idx.view(-1), rows_in=w.Me, rows_out=w.Me)
         x = w.enc_x0
         for W, L in zip(self.encW, w.enc):
