@@ -155,6 +155,10 @@ int mofo_fp8_update_scales(float* amax, float* scales, int n, float margin, void
  * and engine_for_pretraining.py:63 (which cost a device->host sync in the reference).  mask: uint8 [B,N], 1 = masked.
  * vis_idx [B,n_vis], msk_idx [B,N-n_vis]: ascending token ids per clip.  status[0] |= 1 if a clip's count differs. ---- */
 int mofo_mask_to_indices(const uint8_t* mask, int B, int N, int n_vis, int* vis_idx, int* msk_idx, int* status, void* stream);
+/* Device-side tube masks (the distribution of masking_generator.py:3-24, NOT numpy's random stream):
+ * mask u8 [B, frames * patches_per_frame], 1 = masked; per clip one pattern with exactly n_mask masked patches per frame,
+ * repeated over the frames; clip c of the call uses the key stream (seed, counter + c) -- pass a running clip counter. */
+int mofo_tube_masks(unsigned seed, unsigned counter, int B, int frames, int patches_per_frame, int n_mask, uint8_t* mask, void* stream);
 
 /* ---- on-device ingest (the step BEFORE the path): frames uint8 [B,H,W,T*3] = the reference's Stack()
  * output (transforms.py:346-360) -> clips f32 [B,3,T,H,W] = ((u/255) - mean_c) / std_c, i.e. ToTorchFormatTensor(div=True)

@@ -46,6 +46,39 @@ __global__ __launch_bounds__(256) void mask_idx_kernel(const uint8_t* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------- device-side tube masks
+// the tube mask of masking_generator.py:3-24 drawn ON the device -- one per-frame pattern with exactly
+// n_mask of the P = height x width patches masked, repeated over the F temporal slots -- so that no mask crosses PCIe.  The
+// reference shuffles with numpy's global Mersenne-Twister stream inside DataLoader workers; a device kernel cannot continue that
+// stream, so this is a generator of its own (the host classes in masking_generator.py stay the bit-exact drop-in): patch i of
+// clip c gets the 32-bit key mix32(seed, counter + c, i), the n_mask SMALLEST keys (ties: lower index first) are masked.  Every
+// subset of size n_mask is equally likely up to the quality of the integer mixer; oracle/pretrain_oracle.py restates it in numpy.
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {          // "lowbias32" integer finaliser
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+__global__ __launch_bounds__(256) void tube_mask_kernel(uint32_t seed, uint32_t counter, int F, int P, int n_mask, uint8_t* __restrict__ mask) {
+    __shared__ uint32_t key[1024];
+    __shared__ uint8_t pat[1024];
+    const int c = blockIdx.x;
+    const uint32_t base = mix32(seed ^ mix32(counter + (uint32_t)c + 0x9e3779b9u));
+    for (int i = threadIdx.x; i < P; i += 256) key[i] = mix32(base + 0x85ebca6bu * (uint32_t)(i + 1));
+    __syncthreads();
+    for (int i = threadIdx.x; i < P; i += 256) {
+        const uint32_t k = key[i];
+        int rank = 0;                                            // patches that sort before patch i
+        for (int j = 0; j < P; ++j) rank += (key[j] < k) || (key[j] == k && j < i);
+        pat[i] = rank < n_mask;
+    }
+    __syncthreads();
+    uint8_t* m = mask + (size_t)c * F * P;
+    for (int i = threadIdx.x; i < F * P; i += 256) m[i] = pat[i % P];
+}
+
 // ---------------------------------------------------------------------------------------------- tubelet gather
 // Pixel sources.  F32: the model's input contract, clips f32 [B][C][T][H][W] ImageNet-normalised.  U8 (SURVEY.md 8f rank 3,
 // "ingest fused into the K1 / K12 reads"): the reference's Stack() output per clip, uint8 [B][H][W][T*3], normalised on the
@@ -340,6 +373,16 @@ extern "C" int mofo_ingest_u8(const uint8_t* frames, int B, int T, int H, int W,
     else if (nb % 4 == 0) hipLaunchKernelGGL(ingest_u8_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
     else hipLaunchKernelGGL(ingest_u8_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, frames, T, H, W, clips);
     MOFO_CHECK_LAUNCH("mofo_ingest_u8");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_tube_masks(unsigned seed, unsigned counter, int B, int frames, int patches_per_frame, int n_mask, uint8_t* mask, void* stream) {
+    if (!mask) MOFO_FAIL(MOFO_EINVAL, "mofo_tube_masks: null pointer");
+    if (B <= 0 || frames <= 0 || patches_per_frame <= 0 || patches_per_frame > 1024 || n_mask < 0 || n_mask > patches_per_frame)
+        MOFO_FAIL(MOFO_EINVAL, "mofo_tube_masks: bad sizes (1 <= patches per frame <= 1024, 0 <= n_mask <= patches per frame)");
+    hipLaunchKernelGGL(tube_mask_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, (uint32_t)seed, (uint32_t)counter, frames, patches_per_frame,
+                       n_mask, mask);
+    MOFO_CHECK_LAUNCH("mofo_tube_masks");
     return MOFO_OK;
 }
 

@@ -65,3 +65,29 @@ class TubeMaskingGenerator_BB(_TubeGeometry):
         np.random.shuffle(fill)
         pattern[fill[:budget - len(forced)]] = 1
         return self._tube(pattern)
+
+
+class DeviceTubeMaskingGenerator(_TubeGeometry):
+    """Tube masks drawn ON the device for a whole batch (no mask crosses PCIe; not in the reference).
+    Same distribution as TubeMaskingGenerator -- per clip one pattern with exactly ``num_masks_per_frame`` masked patches per
+    frame, repeated over the temporal slots, every subset equally likely -- but its OWN random stream (a counter-based integer
+    mixer keyed by ``seed`` and a running clip counter; ``oracle.pretrain_oracle.device_tube_masks`` restates it): the
+    reference's masks come from numpy's global Mersenne-Twister inside DataLoader workers, which a kernel cannot continue, so
+    runs that must reproduce the reference's masks keep the host class above.
+
+        gen = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=0)
+        mask = gen(batch_size, out=model.input_buffers(batch_size, n_vis)[1])     # uint8 [B, 1568] on the device, 1 = masked
+    """
+
+    def __init__(self, input_size, mask_ratio, seed=0):
+        super().__init__(input_size, mask_ratio)
+        self.seed, self.clips_drawn = int(seed), 0
+
+    def __call__(self, batch_size, out=None, device=None):
+        import torch
+        from . import ops
+        if out is None:
+            out = torch.empty(batch_size, self.total_patches, dtype=torch.uint8, device=device or "cuda")
+        ops.tube_masks(self.seed, self.clips_drawn, self.frames, self.num_patches_per_frame, self.num_masks_per_frame, out)
+        self.clips_drawn += batch_size
+        return out

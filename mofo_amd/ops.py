@@ -415,6 +415,16 @@ def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
     _run("mofo_mask_to_indices", ("mask_idx",), 5.0 * B * N, _p(mask_u8), B, N, n_vis, _p(vis_idx), _p(msk_idx), _p(status))
 
 
+def tube_masks(seed, counter, frames, patches_per_frame, n_mask, mask_u8):
+    """device-side tube masks (include/mofo_hip.h: mofo_tube_masks): fills mask_u8 [B, frames * patches_per_frame]"""
+    _chk(mask_u8, U8, "mask", 2)
+    B, N = mask_u8.shape
+    if not mask_u8.is_contiguous() or N != frames * patches_per_frame:
+        raise ValueError("tube_masks: mask must be contiguous [B, frames * patches_per_frame]")
+    _run("mofo_tube_masks", ("tube_masks",), 1.0 * B * N, int(seed) & 0xFFFFFFFF, int(counter) & 0xFFFFFFFF, B, frames, patches_per_frame, n_mask,
+         _p(mask_u8))
+
+
 def patch_gather(clips, pt, p, tok_idx, out):
     _chk(clips, F32, "clips", 5), _chk(tok_idx, I32, "tok_idx", 2), _chk(out, BF16, "out", 2)
     B, Cc, T, H, W = clips.shape

@@ -495,3 +495,31 @@ def train_step(x: torch.Tensor, mask: torch.Tensor, P: Dict[str, torch.Tensor], 
         with torch.no_grad():
             adamw_step(P, grads, st, lr, weight_decay)
     return float(loss.detach()), float(gn), grads
+
+
+# ---------------------------------------------------------------------------------------------- device-side tube masks
+def _mix32(x):
+    """the "lowbias32" integer finaliser of mofo_amd/csrc/tokens.hip (uint32 arithmetic)"""
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7feb352d) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846ca68b) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def device_tube_masks(seed, counter, B, frames, patches_per_frame, n_mask):
+    """CPU restatement of mofo_tube_masks (the build's OWN generator for SURVEY.md 8f rank 3; the reference's tube mask,
+    masking_generator.py:3-24, fixes the DISTRIBUTION it must have: n_mask of the patches of a frame, one pattern per clip
+    repeated over the frames).  Returns uint8 [B, frames * patches_per_frame], 1 = masked."""
+    out = np.zeros((B, frames * patches_per_frame), dtype=np.uint8)
+    i = np.arange(patches_per_frame, dtype=np.uint64)
+    for c in range(B):
+        base = _mix32((seed & 0xFFFFFFFF) ^ int(_mix32((counter + c + 0x9e3779b9) & 0xFFFFFFFF)))
+        key = _mix32((int(base) + 0x85ebca6b * (i + 1)) & 0xFFFFFFFF)
+        order = np.lexsort((i, key))                     # ascending key, ties by index
+        pat = np.zeros(patches_per_frame, dtype=np.uint8)
+        pat[order[:n_mask]] = 1
+        out[c] = np.tile(pat, frames)
+    return out

@@ -35,6 +35,25 @@ def test_mask_generators_match_reference_fixtures():
     assert "total patches 1568, mask patches 1408" in repr(gen)
 
 
+def test_device_tube_mask_generator_distribution():
+    """the oracle's restatement of the device-side tube-mask generator has the reference generator's
+    structure and draws every patch with the same frequency (the GPU test compares the kernel with it bit for bit)"""
+    from oracle import pretrain_oracle as O
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    host = TubeMaskingGenerator((8, 14, 14), 0.9)
+    m = O.device_tube_masks(5, 0, 6, 8, 196, host.num_masks_per_frame)
+    ref = host()
+    assert m.shape == (6, ref.size) and (m.sum(1) == ref.sum()).all()
+    assert (m.reshape(6, 8, 196) == m.reshape(6, 8, 196)[:, :1]).all()
+    many = O.device_tube_masks(5, 0, 4000, 1, 196, 176).astype(np.float64)
+    freq = many.mean(0)                                   # each patch masked with probability 176 / 196
+    assert abs(freq.mean() - 176 / 196) < 1e-12
+    assert np.abs(freq - 176 / 196).max() < 5 * np.sqrt((176 / 196) * (20 / 196) / 4000)
+    pair = (many[:, :98] * many[:, 98:]).mean(0)          # pairs: P(both masked) = 176 * 175 / (196 * 195)
+    assert abs(pair.mean() - 176 * 175 / (196 * 195)) < 2e-3
+    assert np.array_equal(O.device_tube_masks(5, 3, 2, 8, 196, 176), O.device_tube_masks(5, 0, 5, 8, 196, 176)[3:])
+
+
 def test_bb_mask_edge_cases():
     from mofo_amd.masking_generator import TubeMaskingGenerator_BB
     gen = TubeMaskingGenerator_BB((8, 14, 14), 0.9, 0.75)

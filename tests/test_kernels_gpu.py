@@ -579,6 +579,44 @@ def test_attention_spiky_softmax(dev):
 
 
 # ------------------------------------------------------------------------------------------------ token plumbing
+@pytest.mark.parametrize("grid,ratio", [((8, 14, 14), 0.9), ((16, 14, 14), 0.9), ((8, 2, 2), 0.75), ((1, 32, 32), 0.5)])
+def test_device_tube_masks(dev, grid, ratio):
+    """device-side tube masks against the oracle's numpy restatement of the same generator, bit for bit,
+    plus the reference's structure: exactly int(ratio * patches) masked per frame, one pattern per clip in every temporal slot,
+    a running clip counter (two calls of 3 and 4 clips == one call of 7), and the masks drive a training step like host masks"""
+    from mofo_amd import ops
+    from mofo_amd.masking_generator import DeviceTubeMaskingGenerator, TubeMaskingGenerator
+    from oracle import pretrain_oracle as O
+    F, Hh, Ww = grid
+    P = Hh * Ww
+    gen = DeviceTubeMaskingGenerator(grid, ratio, seed=123)
+    host = TubeMaskingGenerator(grid, ratio)
+    assert gen.num_masks_per_frame == host.num_masks_per_frame and repr(gen) == repr(host)
+    a = gen(3, device=dev)
+    b = gen(4, device=dev)
+    got = torch.cat([a, b]).cpu().numpy()
+    want = O.device_tube_masks(123, 0, 7, F, P, gen.num_masks_per_frame)
+    assert got.dtype == np.uint8 and np.array_equal(got, want)
+    per_frame = got.reshape(7, F, P)
+    assert (per_frame.sum(-1) == gen.num_masks_per_frame).all()
+    assert (per_frame == per_frame[:, :1]).all()
+    if P >= 100:
+        assert len({r.tobytes() for r in got}) == 7                               # clips differ (4 patches only have 4 patterns)
+    again = DeviceTubeMaskingGenerator(grid, ratio, seed=123)(7, device=dev).cpu().numpy()
+    assert np.array_equal(again, got)                                             # deterministic in (seed, clip counter)
+    other = DeviceTubeMaskingGenerator(grid, ratio, seed=124)(7, device=dev).cpu().numpy()
+    assert P < 100 or not np.array_equal(other, got)
+    # the index lists of such a mask
+    nv = F * (P - gen.num_masks_per_frame)
+    vis = torch.empty(7, nv, dtype=torch.int32, device=dev)
+    msk = torch.empty(7, F * P - nv, dtype=torch.int32, device=dev)
+    st = torch.zeros(1, dtype=torch.int32, device=dev)
+    ops.mask_to_indices(torch.from_numpy(got).to(dev), nv, vis, msk, st)
+    assert int(st.item()) == 0 and vis[0].cpu().tolist() == np.nonzero(got[0] == 0)[0].tolist()
+    with pytest.raises(RuntimeError, match="bad sizes"):
+        ops.tube_masks(0, 0, 1, 2048, 2049, torch.empty(1, 2048, dtype=torch.uint8, device=dev))
+
+
 def test_mask_to_indices(dev):
     from mofo_amd import ops
     from oracle import pretrain_oracle as O
