@@ -322,6 +322,24 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     }
 }
 
+// LDS-DMA (global -> LDS, no VGPR destination) as inline asm: invisible to hipcc's wait-count bookkeeping, so the loads of
+// the NEXT query block can stay in flight across the barriers of a whole block (7 steps) and are drained by one explicit
+// `s_waitcnt vmcnt(0)` before the block's last barrier.  Register staging (load at the top of a step, ds_write at its end)
+// made every step as long as a loaded chip's global-load latency: 4 700 clk for 640 clk of MFMA.  M0 = LDS byte address of
+// the wave's 1 KiB (dwordx4) / 256 B (dword) piece; lane l lands at + 16 l / + 4 l; the source address is per lane.
+__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a query row beyond N: p = exp2(-big) = 0, delta = 0
+
+
 // ------------------------------------------------------------------------------------------------ dK, dV
 // Measured on the decoder shape (tools/attn_ab.py, one process): two-tile unrolling with compile-time buffer parity -4.9 %;
 // raised MFMA priority here +5 % (two waves per SIMD: the partner's VALU is what overlaps); -delta pre-loaded into the dP
@@ -346,6 +364,9 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     constexpr bool PRELOAD = U2;
     constexpr bool PRELOAD_C = U2;
     constexpr bool PAIR = U2 && !WHOLE;    // two query tiles staged per barrier (four LDS tile buffers): -2 %
+    // ... by LDS-DMA: no staging registers (240 -> 226 VGPRs), no ds_write pass, no wait for the loads at the write: -2.8 %.  (The
+    // same staging in the forward / dQ kernel, one K / V tile per barrier: +1.8 % / 0 %, not kept there.)
+    constexpr bool DMA = PAIR && NW >= 4;
     // per buffer: Q tile, dO tile, then 32 f32 lse2 + 32 f32 delta
     constexpr int BUF = 2 * TILE + 256;
     constexpr int NBUF = WHOLE ? 5 : (PAIR ? 4 : 2);
@@ -408,6 +429,32 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         lwrite_from(2 * pb, qreg, oreg, sreg);
         lwrite_from(2 * pb + 1, qreg2, oreg2, sreg2);
     };
+    // LDS-DMA form: waves 0..3 each move one 8-row piece of the Q and dO tiles of both query tiles of pair pr straight into pair
+    // buffer pb (the XOR swizzle is applied to the per-lane SOURCE chunk: DMA writes are lane-linear); wave 0 also moves the two
+    // (lse2 | delta) rows, rows beyond the sequence read the pad values
+    auto dma_pair = [&](int pr, int pb) {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        if (wave_u < 4) {
+            const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem) + (unsigned)(2 * pb) * BUF;
+            const int rl = wave_u * 8 + (lane >> 3);
+            const int ch = (lane & 7) ^ swz(rl);
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                int r = (2 * pr + u) * 32 + rl;
+                r = r < N ? r : N - 1;
+                dma_b128(qp + (size_t)r * ldqkv + ch * 8, lds0 + u * BUF + wave_u * 1024);
+                dma_b128(dop + (size_t)r * lddo + ch * 8, lds0 + u * BUF + TILE + wave_u * 1024);
+            }
+            if (wave_u == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int qq = (2 * pr + u) * 32 + (lane & 31);
+                    const float* src = lane < 32 ? (qq < N ? lp + qq : g_pad_row) : (qq < N ? dp_ + qq : g_pad_row + 1);
+                    dma_b32(src, lds0 + u * BUF + 2 * TILE);
+                }
+            }
+        }
+    };
     if constexpr (WHOLE) {
         for (int qt = 0; qt < nqt; ++qt) {
             gload(qt);
@@ -415,13 +462,20 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         }
         __syncthreads();
     } else if constexpr (PAIR) {
-        gload2(0);
-        lwrite2(0);
+        if constexpr (DMA) {
+            dma_pair(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            gload2(0);
+            lwrite2(0);
+        }
         if (stagger > 0 && wave == 0 && (__builtin_amdgcn_s_getreg(6148) & 1)) {
             for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
         }
         __syncthreads();
-        if (nqt > 2) gload2(1);
+        if constexpr (!DMA) {
+            if (nqt > 2) gload2(1);
+        }
     } else {
         gload(0);
         lwrite(0);
@@ -532,11 +586,20 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         const int npair = (nqt + 1) >> 1;
         auto pair = [&](int pr, auto pb_tag) {
             constexpr int PB = decltype(pb_tag)::value;
+            if constexpr (DMA) {
+                // the other pair buffer is free (the barrier that ended the previous pair): its DMA is in flight for the whole pair
+                if (pr + 1 < npair) dma_pair(pr + 1, PB ^ 1);
+            }
             qtile(2 * pr, std::integral_constant<int, 2 * PB>{});
             if (2 * pr + 1 < nqt) qtile(2 * pr + 1, std::integral_constant<int, 2 * PB + 1>{});
-            if (pr + 1 < npair) lwrite2(PB ^ 1);
-            __syncthreads();
-            if (pr + 2 < npair) gload2(pr + 2);
+            if constexpr (DMA) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces have landed; the barrier covers the others'
+                __syncthreads();
+            } else {
+                if (pr + 1 < npair) lwrite2(PB ^ 1);
+                __syncthreads();
+                if (pr + 2 < npair) gload2(pr + 2);
+            }
         };
         int pr = 0;
         for (; pr + 1 < npair; pr += 2) {
@@ -769,23 +832,6 @@ __global__ __launch_bounds__(FUSED_NW * 64) void attn_bwd_fused_kernel(const bf1
 // final bf16 rounding (guide, "Global float atomics") -- inside the 2e-2 bound of the kernel test.
 // LDS: the query block's Q / dO tiles + (lse2, delta) rows double-buffered (the next block is loaded one tile per step),
 // the strip's K tiles, the scratch: OP_T x 23 040 B = 161 280 B for OP_T = 7 -> one block per CU, 7 waves.
-// LDS-DMA (global -> LDS, no VGPR destination) as inline asm: invisible to hipcc's wait-count bookkeeping, so the loads of
-// the NEXT query block can stay in flight across the barriers of a whole block (7 steps) and are drained by one explicit
-// `s_waitcnt vmcnt(0)` before the block's last barrier.  Register staging (load at the top of a step, ds_write at its end)
-// made every step as long as a loaded chip's global-load latency: 4 700 clk for 640 clk of MFMA.  M0 = LDS byte address of
-// the wave's 1 KiB (dwordx4) / 256 B (dword) piece; lane l lands at + 16 l / + 4 l; the source address is per lane.
-__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma_b32(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a query row beyond N: p = exp2(-big) = 0, delta = 0
-
 constexpr int OP_T = 7;
 constexpr int OP_QBUF = OP_T * (2 * TILE + 256);                      // one query block: Q tiles, dO tiles, [32 lse2 | 32 delta] rows
 constexpr int OP_SMEM = 2 * OP_QBUF + OP_T * TILE + OP_T * 32 * SCR;  // 161 280 B
