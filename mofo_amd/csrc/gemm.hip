@@ -182,7 +182,66 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
         __builtin_amdgcn_wave_barrier();
     };
 
-    if constexpr (OUT_BF16) {
+    if constexpr (EPI == MOFO_EPI_BF16) {
+        // Plain bf16 output: bias is added and the tile rounded IN THE FRAGMENT LAYOUT (a lane holds 4 consecutive n of one m),
+        // so the staging area carries bf16 -- twice the rows per pass of the f32 form (the persistent kernel: 2 passes of 32
+        // rows instead of 4 of 16; every pass is a write -> read -> store latency chain), half the LDS bytes, and 8-byte
+        // writes (6 LDS cycles) instead of 16-byte ones (13).  Image: 128-B rows; 16-B chunk c of row r at c ^ (r & 7), the
+        // 8-B half h inside it at h ^ ((r >> 3) & 1): writes (16 rows x 8 B per lane group) and ds_read_b128 row reads are
+        // both bank-conflict free; the reader un-swaps the halves by register naming (the bit is the read's index parity).
+        constexpr int BROWS = (2 * PROWS < WROWS) ? 2 * PROWS : WROWS;    // rows per pass
+        constexpr int BPASS = WROWS / BROWS;
+        unsigned char* eb = (unsigned char*)ep;
+        const int r16 = lane & 15, c4g = lane >> 4;
+        f32x4 bf[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = nb + 16 * j + 4 * c4g;
+            bf[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (p.bias && n < p.N) bf[j] = *(const f32x4*)(p.bias + n);
+        }
+        const int rr = lane >> 3, ch = lane & 7;
+        const int n = nb + ch * 8;
+        const bool ncol = n < p.N;
+        auto run = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+        for (int ps = 0; ps < BPASS; ++ps) {
+            if (ps) __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int ii = 0; ii < BROWS / 16; ++ii) {
+                const int i = ps * (BROWS / 16) + ii;
+                const int row = 16 * ii + r16;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    f32x4 v = acc[i][j];
+                    if constexpr (SCALED) v = v * alpha;
+                    v += bf[j];
+                    const int c = 2 * j + (c4g >> 1), h = c4g & 1;
+                    *(u32x2*)(eb + row * 128 + ((c ^ (row & 7)) << 4) + ((h ^ ((row >> 3) & 1)) << 3)) =
+                        u32x2{pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (ps == 0 && stamp) MOFO_TRACE(3);
+            u32x4 t[BROWS / 8];
+#pragma unroll
+            for (int g = 0; g < BROWS / 8; ++g) {
+                const int row = 8 * g + rr;
+                t[g] = *(const u32x4*)(eb + row * 128 + ((ch ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int g = 0; g < BROWS / 8; ++g) {
+                const u32x4 o = (g & 1) ? u32x4{t[g][2], t[g][3], t[g][0], t[g][1]} : t[g];
+                const int m = mb + ps * BROWS + 8 * g + rr;
+                if (FULL || (ncol && m < p.M)) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        };
+        if (full_tile) run(std::true_type{});
+        else run(std::false_type{});
+    } else if constexpr (OUT_BF16) {
         const int cg = lane & 7;
         const int n = nb + cg * 8;
         const bool ncol = n < p.N;
