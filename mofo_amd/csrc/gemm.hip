@@ -260,7 +260,15 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                 for (int g = 0; g < NG; ++g) {
                     const int m = mb + g * 8 + (lane >> 3);
                     h[g] = u32x4{0u, 0u, 0u, 0u};
-                    if (FULL || (ncol && m < p.M)) h[g] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+#ifndef MOFO_GEMM_NT_AUX
+#define MOFO_GEMM_NT_AUX 1
+#endif
+                    if (FULL || (ncol && m < p.M)) {
+                        // dGELU: the saved pre-activation is read here for the last time -- non-temporally, so that it does not push
+                        // the gradient this kernel writes (and the next GEMM reads) out of the Infinity Cache
+                        if constexpr (EPI == MOFO_EPI_DGELU_BF16 && MOFO_GEMM_NT_AUX) h[g] = __builtin_nontemporal_load((const u32x4*)(p.aux + (size_t)m * p.ldaux + n));
+                        else h[g] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                    }
                 }
             }
 #pragma unroll
@@ -290,7 +298,16 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                 }
                 const u32x4 o = {pack_bf16x2(v0[0], v0[1]), pack_bf16x2(v0[2], v0[3]), pack_bf16x2(v1[0], v1[1]), pack_bf16x2(v1[2], v1[3])};
                 const bool ok = FULL || (ncol && m < p.M);
-                if (ok) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+#ifndef MOFO_GEMM_NT_H1
+#define MOFO_GEMM_NT_H1 1
+#endif
+                if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_NT_H1) {
+                    // the pre-activation is not read again before the backward pass: stored non-temporally, it leaves the Infinity
+                    // Cache to the activation (C2) that the next GEMM reads (308 MB of outputs per decoder fc1 for 256 MB of cache)
+                    if (ok) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n));
+                } else {
+                    if (ok) *(u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n) = o;
+                }
                 if constexpr (EPI == MOFO_EPI_BIAS_GELU) {
                     const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
                     const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
