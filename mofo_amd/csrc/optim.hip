@@ -51,11 +51,21 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         gm *= fminf(coef, 1.0f);
     }
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
-        f32x4 pv = ((f32x4*)p)[i];
-        const f32x4 g0 = ((const f32x4*)g)[i];
+#ifndef MOFO_ADAMW_NT
+#define MOFO_ADAMW_NT 1
+#endif
+#if MOFO_ADAMW_NT
+#define ALD(ptr) __builtin_nontemporal_load(ptr)
+#define AST(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define ALD(ptr) (*(ptr))
+#define AST(ptr, val) (*(ptr) = (val))
+#endif
+        f32x4 pv = ALD((f32x4*)p + i);
+        const f32x4 g0 = ALD((const f32x4*)g + i);
         ssq += g0[0] * g0[0] + g0[1] * g0[1] + g0[2] * g0[2] + g0[3] * g0[3];
         const f32x4 gv = g0 * gm;
-        f32x4 mv = ((f32x4*)m)[i], vv = ((f32x4*)v)[i];
+        f32x4 mv = ALD((f32x4*)m + i), vv = ALD((f32x4*)v + i);
         const bool g1 = chunk_group[i >> 8] != 0;
         const float lr = g1 ? lr1 : lr0;
         const float decay = 1.0f - lr * (g1 ? wd1 : wd0);
@@ -67,9 +77,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             const float denom = sqrtf(vv[e]) * inv_sqrt_bc2 + eps;
             pv[e] = pv[e] * decay - step_size * (mv[e] / denom);
         }
-        ((f32x4*)p)[i] = pv;
-        ((f32x4*)m)[i] = mv;
-        ((f32x4*)v)[i] = vv;
+        AST((f32x4*)p + i, pv);          // masters and moments: not touched again before the next update
+        AST((f32x4*)m + i, mv);
+        AST((f32x4*)v + i, vv);
         if (pb) {
             u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             ((u32x2*)pb)[i] = pk;
