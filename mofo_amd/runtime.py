@@ -802,7 +802,9 @@ class PretrainRuntime:
         # the head's weight gradient (36 tiles) joins the first decoder block's grouped launch on the side stream
         S.pending.append((dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"), (0, 0)))
         # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
-        ops.host_op(lambda: S.ring[0].zero_())
+        # (only those rows: the LayerNorm backward below writes the other n_ret rows of every clip)
+        head_zero = S.ring[0].view(w.B, w.N, d.dec_dim)[:, :w.N - n_ret]
+        ops.host_op(lambda: head_zero.zero_())
         self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
                      s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         j = 0
