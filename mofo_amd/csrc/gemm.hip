@@ -875,6 +875,8 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
                                (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false, alpha);
 }
 
+#include "gemm8.h"
+
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
 // (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
 //   wgrad (TN)            VAR 1: 2.30 ms/step vs 2.69 for VAR 0 (3 blocks per CU; fits 168 VGPRs since the SRD staging)
@@ -891,8 +893,36 @@ static int forced_variant() {
     return forced;
 }
 
+// which (layouts, epilogue) pairs the 256 x 256 counted-vmcnt kernel (gemm8.h) is built for
+template <int LA, int LB, int EPI>
+constexpr bool gemm8_built() {
+    if (LA == OPL_ROW && LB == OPL_ROW)
+        return EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_RESID_BF16 || EPI == MOFO_EPI_F32;
+    if (LA == OPL_ROW && LB == OPL_COL) return EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_DGELU_BF16;
+    if (LA == OPL_COL && LB == OPL_COL) return EPI == MOFO_EPI_F32;
+    return false;
+}
+static bool gemm8_has(int op, int epi) {
+    if (op == MOFO_GEMM_NT) return epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_RESID_F32 || epi == MOFO_EPI_RESID_BF16 || epi == MOFO_EPI_F32;
+    if (op == MOFO_GEMM_NN) return epi == MOFO_EPI_BF16 || epi == MOFO_EPI_DGELU_BF16;
+    if (op == MOFO_GEMM_TN) return epi == MOFO_EPI_F32;
+    return false;
+}
+
 template <int LA, int LB, int EPI>
 int launch(const GroupP& g, int mi, hipStream_t s) {
+    if (mi == 16) {
+        if constexpr (gemm8_built<LA, LB, EPI>()) {
+            const int total = g.start[g.count];
+            const char* e = getenv("MOFO_GEMM8_GRID");   // persistent blocks (tests force a few so that every block walks several tiles)
+            const int cap = e && atoi(e) > 0 ? atoi(e) : 256;
+            hipLaunchKernelGGL((gemm8_kernel<LA, LB, EPI>), dim3(total < cap ? total : cap), dim3(512), 0, s, g, total);
+            MOFO_CHECK_LAUNCH("mofo_gemm(gemm8)");
+            return MOFO_OK;
+        } else {
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: the 256-tile kernel is not built for this (op, epilogue)");
+        }
+    }
     const int forced = forced_variant();
     const dim3 grid(g.start[g.count]), block(256);
     if constexpr (LA == OPL_ROW) {
@@ -937,7 +967,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
 
 }  // namespace
 
-static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) {
+static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& blocks) {
     if (!a->A || !a->B || !a->C) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null operand");
     if (a->M <= 0 || a->N <= 0 || a->K <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: non-positive dims %d %d %d", a->M, a->N, a->K);
     const int op = a->op, epi = a->epilogue;
@@ -1010,7 +1040,7 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int& blocks) 
         p.rotate_tile = rt;
     }
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
-    blocks = ceil_div(a->M, bm) * ceil_div(a->N, BN) * splits;
+    blocks = ceil_div(a->M, bm) * ceil_div(a->N, bn) * splits;
     return MOFO_OK;
 }
 
@@ -1054,6 +1084,18 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
     MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: op %d with epilogue %d is not built", op, epi);
 }
 
+// Shapes routed to the 256 x 256 kernel by default, from same-process A/B timings on MI355X (tools/gemm8_ab.py,
+// profiles/r03_gemm8_ab.txt): it wins where a block walks several 256 x 256 tiles of a DEEP reduction (8192^3: 1 341-1 377 vs
+// 833-864 TFLOP/s) and loses at every shape of the ViT-B / ViT-L step (K = 384 ... 4096 with 5 120 ... 100 352 token rows:
+// 0.42-0.97 x): one block per CU cannot overlap its (HBM-heavy) epilogue with another block's main loop, and all CUs reach their
+// epilogues together.  DESIGN.md section 4c.
+static bool gemm8_wanted(const mofo_gemm_args* a, int count) {
+    if (count != 1 || a[0].op == MOFO_GEMM_TN) return false;
+    const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, 256);
+    // measured: 8192^2 x 4096 1.54 x, 16384 x 4096 x 4096 1.34 x, 8192^3 1.59 x (NN 1.65 x), 4096^2 x 16384 1.10 x; 4096^3 0.97 x
+    return a[0].N % 256 == 0 && ((t256 >= 1024 && a[0].K >= 4096) || (t256 >= 256 && a[0].K >= 16384));
+}
+
 extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* stream) {
     if (!a || count < 1 || count > MAXG) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d", MAXG);
     GroupP g;
@@ -1084,10 +1126,21 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
             if (mi8 == 1 || eff8 > 1.25 * eff4) mi = 8;
         }
     }
+    // 256 x 256 counted-vmcnt kernel (gemm8.h).  MOFO_GEMM8 = 0: never, 1: wherever it is built and legal, unset: by shape.
+    {
+        const char* e = getenv("MOFO_GEMM8");    // read per call: A/B switches inside one process (tools/gemm8_ab.py)
+        const int mode = e ? atoi(e) : -1;
+        bool legal = mode != 0 && gemm8_has(a[0].op, a[0].epilogue);
+        for (int i = 0; legal && i < count; ++i) {
+            // NT / NN stream whole K-tile PAIRS of a k-contiguous operand: a K-tile past the end would read the next row, not zeros
+            if (a[i].op != MOFO_GEMM_TN && (a[i].K % 128 || a[i].splits > 1)) legal = false;
+        }
+        if (legal && (mode == 1 || gemm8_wanted(a, count))) mi = 16;
+    }
     for (int i = 0; i < count; ++i) {
         if (a[i].op != a[0].op || a[i].epilogue != a[0].epilogue) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: problems must share op and epilogue");
         int blocks = 0;
-        const int rc = fill_problem(&a[i], g.p[i], 32 * mi, blocks);
+        const int rc = fill_problem(&a[i], g.p[i], mi == 16 ? 256 : 32 * mi, mi == 16 ? 256 : BN, blocks);
         if (rc) return rc;
         g.start[i + 1] = g.start[i] + blocks;
     }

@@ -273,6 +273,62 @@ def test_gemm_grouped_wgrad(dev):
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, big + probs[:1])
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (512, 768, 384), (704, 1152, 256), (1000, 520, 768), (2048, 256, 1536)])
+def test_gemm8_counted_vmcnt_family(dev, monkeypatch, M, N, K):
+    """The 256 x 256 counted-vmcnt kernel (csrc/gemm8.h), forced with MOFO_GEMM8=1, for every (op, epilogue) it is built for, on
+    whole and ragged tiles and several tiles per block, against fp32 torch on the same bf16 operands -- element-wise, so that a
+    half-tile read before its DMA landed (a race that a norm would average away) shows."""
+    from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM8", "1")
+    monkeypatch.setenv("MOFO_GEMM8_GRID", "3")     # few persistent blocks: every block walks several tiles (stream across tiles)
+
+    def close(C, want, tol=2.5e-2):
+        want = want.float()
+        bad = ((C.float() - want).abs() > tol * want.abs().max()).sum().item()
+        assert bad == 0, f"{bad} elements off"
+        assert _rel(C, want) < 6e-3
+
+    A = _rand((M, K), dev, 1)
+    B = _rand((N, K), dev, 2, 0.05)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    ref = A.float() @ B.float().t()
+    Cb = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, B, Cb, bias=bias)
+    close(Cb, ref + bias)
+    C2 = torch.empty_like(Cb)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, A, B, Cb, C2=C2, bias=bias)
+    close(Cb, ref + bias)
+    close(C2, torch.nn.functional.gelu(ref + bias))
+    R = _rand((M, N), dev, 4, 1.0, F32)
+    Cf = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, B, Cf, bias=bias, resid=R)
+    close(Cf, ref + bias + R)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, A, B, Cb, bias=bias, aux=R.to(BF16))
+    close(Cb, ref + bias + R.to(BF16).float())
+    ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf)
+    close(Cf, ref)
+    ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf, accumulate=True)
+    close(Cf, 2 * ref)
+    # dgrad (NN): B is read reduction-strided
+    Bn = B.t().contiguous()                      # [K, N]
+    ops.gemm(ops.GEMM_NN, ops.EPI_BF16, A, Bn, Cb)
+    close(Cb, ref)
+    H = _rand((M, N), dev, 5, 1.0)
+    h = H.float().requires_grad_(True)
+    g, = torch.autograd.grad(torch.nn.functional.gelu(h).sum(), h)
+    ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, A, Bn, Cb, aux=H)
+    close(Cb, ref * g)
+    # wgrad (TN): both operands reduction-strided, split-K with atomics, any reduction length (here K + 8 rows)
+    At = _rand((K + 8, M), dev, 6, 0.1)
+    Bt = _rand((K + 8, N), dev, 7, 0.1)
+    want = At.float().t() @ Bt.float()
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, At, Bt, Cf)
+    close(Cf, want)
+    Cf.zero_()
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, At, Bt, Cf, splits=2)
+    close(Cf, want)
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from mofo_amd import ops
     A = _rand((64, 96), dev, 1)
