@@ -23,6 +23,12 @@ def _stream():
     return (s if s is not None else torch.cuda.current_stream()).cuda_stream
 
 
+def launch_stream():
+    """the torch stream object the C-ABI launches currently go to (the override of use_stream, else torch's current stream)"""
+    s = _STREAM_OVERRIDE
+    return s if s is not None else torch.cuda.current_stream()
+
+
 def use_stream(stream):
     """route the following C-ABI launches to ``stream`` (a torch.cuda.Stream) or, with None, back to torch's current
     stream; recorded into launch lists so that a replay switches at the same place"""
@@ -614,6 +620,8 @@ def cast_bf16(src, dst):
 def zero_chunks(buf, chunk_ids):
     """zero the listed 1024-element chunks of a flat f32 buffer (chunk_ids: int32 GPU tensor)"""
     _chk(buf, F32, "buf", 1), _chk(chunk_ids, I32, "chunk_ids", 1)
-    if buf.numel() % 1024 or chunk_ids.numel() == 0:
-        raise ValueError("zero_chunks: buffer of whole 1024-element chunks, non-empty list")
+    if buf.numel() % 1024:
+        raise ValueError("zero_chunks: buffer of whole 1024-element chunks")
+    if chunk_ids.numel() == 0:
+        return              # nothing accumulates: every gradient is overwritten by plain stores
     _run("mofo_zero_chunks", ("zero_grad",), 4096.0 * chunk_ids.numel(), _p(buf), _p(chunk_ids), chunk_ids.numel())

@@ -328,6 +328,8 @@ class PretrainRuntime:
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self._seg_events = [torch.cuda.Event() for _ in range(8)] if self.dev.type == "cuda" else []
+        self._bwd_done = torch.cuda.Event() if self.dev.type == "cuda" else None     # end of a backward's side-stream work
+        self._side_launched = False
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)
         self.ln_ws = torch.empty(2 * 1024 * dmax, dtype=F32, device=self.dev)   # LN-backward dgamma/dbeta block partials
@@ -518,7 +520,12 @@ class PretrainRuntime:
         elif splits > 1:
             for pr in problems:                # f32 atomics onto what zero_grad left there
                 if self.store.mark_accumulated(pr[2]) and not self._accumulate:
-                    pr[2].zero_()              # (recording run only) another workspace's backward had made zero_grads skip it
+                    # (recording run only) another workspace's backward had made zero_grads skip this tensor.  The clear runs
+                    # on the stream the split-K launch below is issued on (the side stream inside _wgrad_flush), so that it is
+                    # ordered before that launch's atomics; a torch op on the CURRENT stream would race with them.
+                    st = ops.launch_stream()
+                    with torch.cuda.stream(st):
+                        pr[2].zero_()
         ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
@@ -597,6 +604,7 @@ class PretrainRuntime:
             self._wgrad_group(group)          # same stream: no fork / join events (each costs ~10 us of queue bubble)
             return
         side = self.side
+        self._side_launched = True        # _backward joins the side stream once more at its end (see there)
         ops.host_op(lambda ev=S.ready[slot]: ev.record(torch.cuda.current_stream()))
         ops.use_stream(side)
         ops.host_op(lambda ev=S.ready[slot]: side.wait_event(ev))
@@ -851,10 +859,18 @@ class PretrainRuntime:
                            lambda: self._loss_forward(w, normalize_target, grad_scale))
 
     def _backward(self, w: NS):
+        self._side_launched = False
         dx_full = self.decoder_backward(w, w.dpred, w.x_full, w.n_msk, defer_ln=self.segment_hook is None)
         d_encout = self.bridge_backward(w, dx_full, w.enc_out)
         self._seg(0)
         self.encoder_backward(w, d_encout)
+        if self._side_launched and self.side is not None:
+            # The decoder pass leaves its side-stream launches to the encoder's final join (defer_ln).  That join only exists when
+            # the encoder's own groups ran on the side stream: with MOFO_WGRAD_STREAM=main_enc nothing waited for the decoder's
+            # weight-gradient GEMMs, and grad-norm / AdamW / the next step's scratch rewrite raced with them.  One event at the
+            # very end of the (in-order) side stream covers every launch of this backward, whatever the stream modes were.
+            side, ev = self.side, self._bwd_done
+            ops.host_op(lambda: (ev.record(side), torch.cuda.current_stream().wait_event(ev)))
 
     def begin_backward(self):
         """decide overwrite vs accumulate for this backward's weight gradients (zero_grad since the last backward?)"""

@@ -231,6 +231,91 @@ def test_grouped_weight_gradient_launches_do_not_change_gradients(dev, monkeypat
                 assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max())), n
 
 
+@pytest.mark.parametrize("mode", ["main", "main_enc", "main_dec"])
+def test_weight_gradient_stream_modes_agree(dev, monkeypatch, mode):
+    """MOFO_WGRAD_STREAM = main / main_enc / main_dec move the encoder's and / or the decoder's grouped weight-gradient launches
+    from the side stream onto the caller's.  With main_enc the encoder's final join of the side stream does not exist, and the
+    decoder's side-stream launches used to have nothing waiting for them before grad-norm / AdamW / the next step's scratch
+    rewrite: the backward now ends in one join of the side stream whatever the modes are.  Two steps each (the second re-uses
+    every scratch buffer), gradients and the norm read right after backward, against the default (side) schedule."""
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(img_size=96, enc_dim=192, enc_depth=4, enc_heads=3, dec_dim=128, dec_depth=2, dec_heads=2)
+    B = 6                                            # decoder: 6 x 288 tokens (n > 512 is the "decoder" side of the switch)
+    x = O.keyed_clips(B, cfg).to(dev)
+    np.random.seed(4)
+    gen = TubeMaskingGenerator(cfg.grid, 0.75)
+    mask = torch.from_numpy(np.stack([gen() for _ in range(B)])).bool().to(dev)
+
+    def run(m):
+        monkeypatch.setenv("MOFO_WGRAD_STREAM", m)
+        model, _ = _build(cfg, "xavier", dev)
+        rt = model.runtime()
+        out = []
+        for _ in range(2):
+            loss = model.forward_loss(x, mask)
+            rt.store.zero_grads()
+            loss.backward()
+            gn = rt.grad_norm().clone()              # enqueued right behind the backward, like the engine does
+            out.append((float(loss), rt.store.grads.clone(), float(gn)))
+        model.check_status()
+        return out, rt.store
+
+    ref, store = run("side")
+    got, _ = run(mode)
+    for (l0, g0, n0), (l1, g1, n1) in zip(ref, got):
+        assert l0 == l1
+        assert n1 == pytest.approx(n0, rel=1e-5)
+        for n in store.names:
+            o, k = store.offset[n], int(np.prod(store.shape[n]))
+            a, b = g0[o:o + k], g1[o:o + k]
+            if len(store.shape[n]) == 2:
+                assert torch.equal(a, b), n
+            else:
+                assert torch.allclose(a, b, rtol=1e-4, atol=1e-6 * float(a.abs().max())), n
+
+
+@pytest.mark.parametrize("order", ["small_first", "large_first"])
+def test_split_and_unsplit_workspaces_share_one_gradient_buffer(dev, monkeypatch, order):
+    """zero_grads() skips tensors that a recorded backward OVERWRITES (unsplit grouped weight gradients).  A second workspace of
+    the same model whose launch of the same tensors is SPLIT adds with f32 atomics -- onto whatever was skipped unless the store
+    is told (mark_accumulated) and the stale contents are cleared once, ON THE STREAM of the split launch.  Batch 1 (few token
+    rows: never split) and batch 16 (split forced through MOFO_WGRAD_THR / MOFO_WGRAD_TARGET), in both orders, three rounds:
+    every gradient equals the one a model gets that always clears everything (MOFO_ZERO_ALL=1)."""
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(img_size=96, enc_dim=192, enc_depth=2, enc_heads=3, dec_dim=128, dec_depth=2, dec_heads=2, num_frames=32)
+    np.random.seed(5)
+    gen = TubeMaskingGenerator(cfg.grid, 0.5)
+    xs = {b: O.keyed_clips(b, cfg).to(dev) for b in (1, 16)}       # decoder rows: 576 (never split) and 9 216 (two splits of >= 4 096)
+    ms = {b: torch.from_numpy(np.stack([gen() for _ in range(b)])).bool().to(dev) for b in (1, 16)}
+    seq = [1, 16, 1, 16, 16, 1] if order == "small_first" else [16, 1, 16, 1, 1, 16]
+    monkeypatch.setenv("MOFO_WGRAD_THR", "100000")       # every group may split ...
+    monkeypatch.setenv("MOFO_WGRAD_TARGET", "2048")      # ... as far as its token rows allow (>= 4096 rows per split)
+
+    def run(zero_all):
+        monkeypatch.setenv("MOFO_ZERO_ALL", "1" if zero_all else "0")
+        model, _ = _build(cfg, "xavier", dev)
+        store = model.runtime().store
+        out = []
+        for b in seq:
+            loss = model.forward_loss(xs[b], ms[b])
+            store.zero_grads()
+            loss.backward()
+            out.append(store.grads.clone())
+        model.check_status()
+        return out, store
+
+    ref, store = run(True)
+    got, store2 = run(False)
+    assert bool(store2._must_zero.any()), "the large batch was expected to split at least one group (test premise)"
+    for step, (g0, g1) in enumerate(zip(ref, got)):
+        for n in store.names:
+            o, k = store.offset[n], int(np.prod(store.shape[n]))
+            a, b = g0[o:o + k], g1[o:o + k]
+            assert torch.allclose(a, b, rtol=2e-4, atol=2e-6 * float(a.abs().max()) + 1e-12), (step, seq[step], n)
+
+
 def _vitb_inputs(dev, which):
     from oracle import pretrain_oracle as O
     m = np.load(os.path.join(G, "masks.npz"))
