@@ -73,11 +73,33 @@ def cpu_baseline(seconds_budget: float):
             "sample": f"oracle fp32 torch-CPU train step, ViT-B dec4, batch 2, {n} timed steps after 1 warm-up ({dt:.1f} s)"}
 
 
+def self_launch(n: int) -> int:
+    """run `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process and relay its output"""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] no launcher in the environment: starting", " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)      # stderr passes through
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if proc.returncode else (0 if line is not None else 1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)      # SURVEY.md 8d: >= 50 timed steps after >= 10 warm-up
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU (BASELINE configs[1]/[2]: 32)")
     ap.add_argument("--mask", choices=["tube", "bb"], default="tube",
                     help="tube: TubeMaskingGenerator 0.9 (configs 1/2); bb: MOFO motion-bounding-box masks, 75%% in-box (config 3)")
@@ -101,8 +123,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes, one per GPU, the way
+            # the reference is launched (PRETRAIN.md:13-16; utils.py:277-296 reads RANK / WORLD_SIZE / LOCAL_RANK).  This parent
+            # has made no GPU call (nothing above touches HIP) and never exec()s: it relays the children's one JSON line and
+            # their return code.
+            return self_launch(args.gpus)
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {args.gpus})")
     # one rank per GPU; MOFO_DIST_BACKEND=gloo rehearses the N > 1 path with several ranks on ONE GPU (RCCL refuses that)
     backend = os.environ.get("MOFO_DIST_BACKEND", "nccl")
     if backend != "nccl":
@@ -381,4 +408,4 @@ def utils_quiet(fn, *a, **k):
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -63,7 +63,8 @@ typedef struct mofo_gemm_args {
     const float* b_scale_inv;
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
-/* up to 4 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of a transformer block) */
+/* up to 13 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of three transformer blocks
+ * and the patch embed's) */
 int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */
@@ -229,6 +230,14 @@ int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, voi
 int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream);
+/* mofo_adamw behind a device-side gate: the kernel leaves p, m, v and p_bf16 untouched (and norm_partial unwritten) unless
+ * gate_finite[0] is finite, gate_zero[0] == 0 and gate_one[0] == 1.0f (each pointer may be NULL = not checked).  The host enqueues
+ * backward and the update before it reads the loss; the reference stops before backward on a non-finite loss
+ * (engine_for_pretraining.py:168-176), so a bad step must not reach the parameters. */
+int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                     float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                     const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                     const float* gate_finite, const int* gate_zero, const float* gate_one, void* stream);
 int mofo_adamw_blocks(long long n);
 int mofo_norm_finalize(const float* partial, int count, float* out_norm, void* stream);
 int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);

@@ -65,6 +65,7 @@ _SIGS = {
     "mofo_token_mean_norm": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp]),
     "mofo_sumsq": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "mofo_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp, _vp]),
+    "mofo_adamw_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "mofo_adamw_blocks": (_i, [_ll]),
     "mofo_norm_finalize": (_i, [_vp, _i, _vp, _vp]),
     "mofo_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),

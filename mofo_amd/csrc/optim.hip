@@ -42,8 +42,16 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
                                                     const uint8_t* __restrict__ chunk_group, float lr0, float wd0, float lr1,
                                                     float wd1, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
                                                     const float* __restrict__ grad_norm, float max_norm, float grad_mult,
-                                                    float* __restrict__ sumsq_partial) {
+                                                    float* __restrict__ sumsq_partial, const float* __restrict__ gate_finite,
+                                                    const int* __restrict__ gate_zero, const float* __restrict__ gate_one) {
     __shared__ float red[4];
+    // Device-side gate (mofo_adamw_gated): the reference stops BEFORE backward on a non-finite loss
+    // (engine_for_pretraining.py:168-170); here the update is already enqueued when the host reads the loss, so the kernel
+    // itself declines to touch masters, moments and the bf16 shadow when the step is bad.  Block-uniform: every thread reads
+    // the same three words.
+    if (gate_finite && !(fabsf(gate_finite[0]) <= 3.402823466e38f)) return;      // NaN or +-inf
+    if (gate_zero && gate_zero[0] != 0) return;                                  // status word set (e.g. ragged mask)
+    if (gate_one && gate_one[0] != 1.0f) return;                                 // fused loss back-propagated with upstream != 1
     float ssq = 0.f;                    // sum of squares of the (unscaled) gradients this thread reads, if asked for
     float gm = grad_mult;
     if (max_norm > 0.f && grad_norm) {
@@ -119,9 +127,10 @@ extern "C" int mofo_sumsq(const float* g, long long n, float* partial, float* ou
     return MOFO_OK;
 }
 
-extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
-                          float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
-                          const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream) {
+extern "C" int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                                const float* gate_finite, const int* gate_zero, const float* gate_one, void* stream) {
     if (!p || !g || !m || !v || !chunk_group) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: null pointer");
     if (n <= 0 || n % 1024) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_adamw: n must be a positive multiple of 1024");
     if (step < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: step starts at 1");
@@ -131,13 +140,20 @@ extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
                        chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
-                       norm_partial);
+                       norm_partial, gate_finite, gate_zero, gate_one);
     MOFO_CHECK_LAUNCH("mofo_adamw");
     if (norm_partial && norm_out) {     // global gradient L2 norm as a by-product of the pass that reads the gradients anyway
         hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)norm_partial, stream_blocks(n / 4), norm_out);
         MOFO_CHECK_LAUNCH("mofo_adamw(norm)");
     }
     return MOFO_OK;
+}
+
+extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                          float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                          const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream) {
+    return mofo_adamw_gated(p, g, m, v, p_bf16, n, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm, max_norm, grad_mult,
+                            norm_partial, norm_out, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int mofo_adamw_blocks(long long n) { return n > 0 ? stream_blocks(n / 4) : 0; }

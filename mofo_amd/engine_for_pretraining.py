@@ -32,7 +32,9 @@ def _step_common(model, videos, bool_masked_pos, optimizer, loss_scaler, max_nor
         raise TypeError("model must be a mofo_amd PretrainVisionTransformer (optionally wrapped in mofo_amd.dist.DataParallel)")
     # The reference reads the loss (a device sync) BEFORE it launches the backward (:69 then :172-176), which leaves the
     # GPU idle for the round trip.  Here backward + grad-norm + AdamW are enqueued first and the loss is read while they
-    # run; a non-finite loss still ends the process at the same place (nothing observes the parameters in between).
+    # run; a non-finite loss still ends the process at the same place, and the update itself is gated ON THE DEVICE by the
+    # loss / status words (mofo_adamw_gated): a step the reference would have stopped before backward (:168-176) leaves
+    # parameters, moments and the bf16 shadow untouched.
     optimizer.zero_grad()
     grad_norm = loss_scaler(loss, optimizer, clip_grad=max_norm, parameters=None, create_graph=False)
     loss_value = loss.item()

@@ -195,7 +195,11 @@ class _ModelFn(torch.autograd.Function):
             # loss.backward() passes); anything else is raised at the next status check.
             # Kept by reference and compared at the status check: doing it here cost four tiny torch launches per step.
             w.upstream = g
+            # the update that follows is gated on the device by these three words (mofo_adamw_gated): finite loss, clear status,
+            # upstream gradient 1 -- a bad step never reaches masters, moments or the bf16 shadow
+            mod._rt.step_gate = (w.loss, w.status, g if (g.is_cuda and g.dtype == torch.float32) else None)
         else:
+            mod._rt.step_gate = (None, w.status, None)
             # generic path (model(x, mask) + a torch loss): under data parallelism the exchange is a SUM all-reduce, so the
             # upstream gradient is scaled by 1/world here -- what forward_loss() folds into the loss kernel's grad_scale --
             # and every rank ends up with DDP's MEAN gradient (run_mae_pretraining.py:225-227) on both paths

@@ -585,8 +585,10 @@ def norm_finalize(partial, count, out_norm):
 
 
 def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0,
-          norm_partial=None, norm_out=None):
-    """``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out"""
+          norm_partial=None, norm_out=None, gate_finite=None, gate_zero=None, gate_one=None):
+    """``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out.
+    ``gate_finite`` (f32 [1]) / ``gate_zero`` (i32 [1]) / ``gate_one`` (f32 [1]): device words the kernel checks before it touches
+    anything -- the update is skipped unless the first is finite, the second 0 and the third 1.0 (mofo_adamw_gated)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
         _chk(t, F32, n, 1)
     _chk(chunk_group, U8, "chunk_group", 1)
@@ -605,8 +607,15 @@ def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps
             raise ValueError("norm_partial must hold adamw_blocks(n) floats (at most 2048)")
     if norm_out is not None:
         _chk(norm_out, F32, "norm_out")
-    _run("mofo_adamw", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
-         lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out))
+    if gate_finite is not None:
+        _chk(gate_finite, F32, "gate_finite")
+    if gate_zero is not None:
+        _chk(gate_zero, I32, "gate_zero")
+    if gate_one is not None:
+        _chk(gate_one, F32, "gate_one")
+    _run("mofo_adamw_gated", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
+         lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out),
+         _p(gate_finite), _p(gate_zero), _p(gate_one))
 
 
 def cast_bf16(src, dst):

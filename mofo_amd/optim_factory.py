@@ -113,6 +113,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 self._norm_partial = torch.empty(2048, dtype=torch.float32, device=st.params.device)
             partial = self._norm_partial
         hyper = (float(g0["lr"]), float(g0["weight_decay"]), float(g1["lr"]), float(g1["weight_decay"]), float(b1), float(b2), float(g0["eps"]), self._step)
+        # device-side gate of this update (set by the backward that produced the gradients; consumed once)
+        gf, gz, go = getattr(rt, "step_gate", None) or (None, None, None)
+        rt.step_gate = None
+        gate = dict(gate_finite=gf, gate_zero=gz, gate_one=go)
         if ranges is not None:
             if max_norm or grad_norm is not None:
                 raise ValueError("range-by-range update is for the un-clipped step")
@@ -136,7 +140,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     wait()
                 nb = ops.adamw_blocks(hi - lo)
                 ops.adamw(st.params[lo:hi], st.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], st.shadow[lo:hi],
-                          st.chunk_group[lo // 1024:hi // 1024], *hyper, norm_partial=self._range_partial[slot:slot + nb] if norm_out is not None else None)
+                          st.chunk_group[lo // 1024:hi // 1024], *hyper, norm_partial=self._range_partial[slot:slot + nb] if norm_out is not None else None,
+                          **gate)
                 slot += nb
                 covered += hi - lo
             if measure:
@@ -147,7 +152,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 ops.norm_finalize(self._range_partial, slot, norm_out)
         else:
             ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group, *hyper, grad_norm=grad_norm,
-                      max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out)
+                      max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out, **gate)
         st.mark_shadow_fresh()
 
     # checkpoint.  Written in torch.optim.AdamW's own state_dict layout -- state[i] = {'step','exp_avg','exp_avg_sq'} with i

@@ -329,6 +329,7 @@ class PretrainRuntime:
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self._seg_events = [torch.cuda.Event() for _ in range(8)] if self.dev.type == "cuda" else []
         self._bwd_done = torch.cuda.Event() if self.dev.type == "cuda" else None     # end of a backward's side-stream work
+        self.step_gate = None            # (loss, status, upstream) device words the next optimizer step is gated on
         self._side_launched = False
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)

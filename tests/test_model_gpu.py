@@ -356,16 +356,19 @@ def test_vitb_engine_step_parity(dev):
         if ref > 1e-3 * float(g["grad_norm"]):
             worst = max(worst, abs(got - ref) / ref)
             assert got == pytest.approx(ref, rel=5e-2), n
-    # element-wise, against the oracle's gradients (the oracle's per-tensor gradient statistics are pinned to the reference's
-    # at 1e-3 by test_oracle_golden.py): the first and last encoder block, a decoder block, the tubelet embedding, the head
-    got_g = {n: grads[n].detach().float().cpu().clone() for n in
-             ("encoder.patch_embed.proj.weight", "encoder.blocks.0.attn.qkv.weight", "encoder.blocks.11.mlp.fc1.weight",
-              "encoder.blocks.11.attn.proj.weight", "encoder_to_decoder.weight", "decoder.blocks.2.mlp.fc2.weight",
-              "decoder.blocks.0.attn.qkv.weight", "decoder.head.weight", "decoder.norm.weight", "mask_token")}
+    # element-wise, ALL 218 tensors, against the oracle's gradients (the oracle's per-tensor gradient statistics are pinned to the
+    # reference's at 1e-3 by test_oracle_golden.py).  Relative Frobenius error per tensor; tensors whose norm is below 1e-3 of the
+    # global norm (a few biases) are held to the same ABSOLUTE error instead.
+    got_g = {n: grads[n].detach().float().cpu().clone() for n in names}
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     _, _, oracle_g = O.train_step(x, mask, P, O.VIT_B)
-    for n, gv in got_g.items():
-        assert _rel(gv, oracle_g[n]) < 6e-2, n
+    total = float(g["grad_norm"])
+    errs = []
+    for n in names:
+        a, b = got_g[n].double().flatten(), oracle_g[n].double().flatten()
+        errs.append((float((a - b).norm()) / max(float(b.norm()), 1e-3 * total), n))
+    errs.sort(reverse=True)
+    assert len(errs) == 218 and errs[0][0] < 6e-2, errs[:8]
     w = model.runtime().ws(2, 160)
     assert _rel(w.pred.view(2, 1408, 1536)[:, :6, :48], g["out_slice"]) < 2e-2
     sd = model.state_dict()
@@ -544,6 +547,44 @@ def test_bad_mask_is_reported(dev):
     model.forward_loss(x, mask.to(dev))
     with pytest.raises(RuntimeError, match="visible tokens"):
         model.check_status()
+
+
+@pytest.mark.parametrize("fault", ["mask", "nan"])
+def test_bad_step_never_reaches_the_parameters(dev, fault):
+    """The engine enqueues backward + AdamW before it reads the loss (the reference reads it first and stops before backward on
+    a non-finite value, engine_for_pretraining.py:168-176).  The update is therefore gated on the device: with a ragged mask
+    (status word) or a NaN clip (non-finite loss) the engine still raises / exits, and masters, Adam moments and the bf16 shadow
+    are bit-for-bit what they were; a good step right before and after updates them."""
+    from mofo_amd import optim_factory, utils
+    from mofo_amd.engine_for_pretraining import train_one_epoch
+    from oracle import pretrain_oracle as O
+    model, _ = _build(O.TINY, "xavier", dev)
+    opt = optim_factory.create_optimizer(_Args(), model)
+    scaler = utils.NativeScalerWithGradNormCount()
+    x = O.keyed_clips(2, O.TINY)
+    good = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).double()
+    st = model.runtime().store
+
+    def epoch(xx, mm):
+        return train_one_epoch(model, [(xx, mm)], opt, dev, 0, scaler, max_norm=None, patch_size=16, start_steps=0)
+
+    epoch(x, good)
+    p0, m0, v0, s0 = st.params.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), st.shadow.clone()
+    if fault == "mask":
+        bad = good.clone()
+        bad[1, 0] = 1.0 - bad[1, 0]                 # clip 1 has one visible token more / less than clip 0
+        with pytest.raises(RuntimeError, match="visible tokens"):
+            epoch(x, bad)
+    else:
+        xn = x.clone()
+        xn[0, 0, 0, 0, 0] = float("nan")
+        with pytest.raises(SystemExit):
+            epoch(xn, good)
+    torch.cuda.synchronize()
+    assert torch.equal(st.params, p0) and torch.equal(opt.exp_avg, m0) and torch.equal(opt.exp_avg_sq, v0) and torch.equal(st.shadow, s0)
+    opt._step -= 1                                   # the refused step does not count
+    epoch(x, good)
+    assert not torch.equal(st.params, p0)
 
 
 def test_bb_engine_and_checkpoint_roundtrip(dev, tmp_path):
@@ -796,6 +837,24 @@ def test_bench_two_ranks_rehearsal(dev):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["value"] == pytest.approx(8 / out["ms_per_step"] * 1e3, rel=1e-3) and math.isfinite(out["config"]["final_loss"])
     assert "cpu_baseline" not in out and "roofline" in out
+
+
+def test_bench_self_launch_two_ranks(dev):
+    """`python bench.py --gpus 2` with NO launcher in the environment (how a driver starts the 1-GPU run): the script starts its
+    two ranks itself as fresh child processes through torch.distributed.run and relays their one JSON line and return code."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "LOCAL_WORLD_SIZE")}
+    env.update({"MOFO_DIST_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "3", "--batch", "4",
+                        "--no-encoder-step"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
 
 
 def test_vit_large_32_frames_parity(dev):
