@@ -184,6 +184,10 @@ int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, 
 int mofo_assemble_bwd_blocks(int B, int N);
 int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d_bf16, float* d_mask_token,
                       float* partial_ws, void* stream);
+/* Deferred form: mofo_assemble_bwd with d_mask_token = NULL only leaves the block partials in partial_ws; this adds them to
+ * d_mask_token (+=).  d(mask_token) is needed by nothing before the optimizer, so the caller can take the tiny reduce launch
+ * off the activation-gradient chain (it used to wait ~180 us for a CU slot behind a weight-gradient launch). */
+int mofo_assemble_bwd_finalize(const float* partial_ws, int B, int N, int D, float* d_mask_token, void* stream);
 
 /* ---- reconstruction target + MSE: engine_for_pretraining.py:43-63 (un-normalise, patchify (p0 p1 p2) c,
  * per-(token,channel) standardise with UNBIASED var and 1e-6 after the sqrt, gather masked) and :27,67 (nn.MSELoss).

@@ -58,6 +58,7 @@ _SIGS = {
     "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mofo_assemble_bwd_blocks": (_i, [_i, _i]),
     "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "mofo_assemble_bwd_finalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_patch_gather_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mofo_target_mse_u8": (_i, [_vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp]),
     "mofo_target_mse": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _vp]),

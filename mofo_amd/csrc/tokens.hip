@@ -441,9 +441,18 @@ extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, 
 
 extern "C" int mofo_assemble_bwd_blocks(int B, int N) { return B > 0 && N > 0 ? ceil_div(B * N, RB) : 0; }
 
+extern "C" int mofo_assemble_bwd_finalize(const float* partial_ws, int B, int N, int D, float* d_mask_token, void* stream) {
+    if (!partial_ws || !d_mask_token || B <= 0 || N <= 0 || D <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd_finalize: bad arguments");
+    hipLaunchKernelGGL(add_partials_kernel, dim3(ceil_div(D, 64), COL_SLICES), dim3(256), 0, (hipStream_t)stream, partial_ws, ceil_div(B * N, RB), D,
+                       d_mask_token);
+    MOFO_CHECK_LAUNCH("mofo_assemble_bwd_finalize");
+    return MOFO_OK;
+}
+
 extern "C" int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int N, int n_vis, int D, void* d_e2d,
                                  float* d_mask_token, float* partial_ws, void* stream) {
-    if (!dx_full || !d_e2d || !d_mask_token) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: null pointer");
+    if (!dx_full || !d_e2d || (!d_mask_token && !partial_ws)) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: null pointer");
+    if (!d_mask_token && !(D % 8 == 0 && D <= 512)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_assemble_bwd: the deferred form needs D a multiple of 8, <= 512");
     if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || D > 1024) MOFO_FAIL(MOFO_EINVAL, "mofo_assemble_bwd: bad sizes");
     const int rows = B * N;
     hipStream_t s = (hipStream_t)stream;
@@ -454,6 +463,7 @@ extern "C" int mofo_assemble_bwd(const void* dx_full, int dx_is_bf16, int B, int
         else
             hipLaunchKernelGGL(assemble_bwd_rows_kernel<false>, dim3(nb), dim3(256), 0, s, dx_full, N, n_vis, D, rows, (bf16_t*)d_e2d, partial_ws);
         MOFO_CHECK_LAUNCH("mofo_assemble_bwd");
+        if (!d_mask_token) return MOFO_OK;       // deferred: the caller adds the block partials later (mofo_assemble_bwd_finalize)
         hipLaunchKernelGGL(add_partials_kernel, dim3(ceil_div(D, 64), COL_SLICES), dim3(256), 0, s, (const float*)partial_ws, nb, D, d_mask_token);
         MOFO_CHECK_LAUNCH("mofo_assemble_bwd(partials)");
         return MOFO_OK;

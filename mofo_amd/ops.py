@@ -474,12 +474,26 @@ def assemble_bwd_blocks(B, N):
     return _lib.load().mofo_assemble_bwd_blocks(B, N)
 
 
+def assemble_bwd_finalize(partial_ws, B, N, d_mask_token):
+    """add the block partials a deferred assemble_bwd (d_mask_token=None) left in partial_ws to d_mask_token"""
+    _chk(partial_ws, F32, "partial_ws"), _chk(d_mask_token, F32, "d_mask_token")
+    D = d_mask_token.numel()
+    if partial_ws.numel() < assemble_bwd_blocks(B, N) * D:
+        raise ValueError("assemble_bwd_finalize: partial_ws needs assemble_bwd_blocks(B, N) * D floats")
+    _run("mofo_assemble_bwd_finalize", ("assemble_bwd_fin",), 4.0 * assemble_bwd_blocks(B, N) * D, _p(partial_ws), B, N, D, _p(d_mask_token))
+
+
 def assemble_bwd(dx_full, n_vis, d_e2d, d_mask_token, partial_ws=None):
+    """``d_mask_token`` None (with ``partial_ws``): deferred -- only the block partials are written, assemble_bwd_finalize adds them"""
     if dx_full is None or dx_full.dtype not in (F32, BF16):
         raise TypeError("dx_full must be f32 or bf16")
-    _chk(dx_full, dx_full.dtype, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2), _chk(d_mask_token, F32, "d_mask_token")
+    _chk(dx_full, dx_full.dtype, "dx_full", 3), _chk(d_e2d, BF16, "d_e2d", 2)
     B, N, D = dx_full.shape
-    if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or d_mask_token.numel() != D:
+    if d_mask_token is not None:
+        _chk(d_mask_token, F32, "d_mask_token")
+    elif partial_ws is None or D % 8 or D > 512:
+        raise ValueError("assemble_bwd: the deferred form needs partial_ws and D a multiple of 8, <= 512")
+    if not dx_full.is_contiguous() or d_e2d.shape != (B * n_vis, D) or not d_e2d.is_contiguous() or (d_mask_token is not None and d_mask_token.numel() != D):
         raise ValueError("assemble_bwd: shape mismatch")
     isb = 1 if dx_full.dtype == BF16 else 0
     if partial_ws is not None:

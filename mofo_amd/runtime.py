@@ -329,6 +329,7 @@ class PretrainRuntime:
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self._seg_events = [torch.cuda.Event() for _ in range(8)] if self.dev.type == "cuda" else []
         self._bwd_done = torch.cuda.Event() if self.dev.type == "cuda" else None     # end of a backward's side-stream work
+        self._asm_ready = torch.cuda.Event() if self.dev.type == "cuda" else None
         self.step_gate = None            # (loss, status, upstream) device words the next optimizer step is gated on
         self._side_launched = False
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
@@ -785,7 +786,22 @@ class PretrainRuntime:
 
     def bridge_backward(self, w: NS, dx_full: torch.Tensor, enc_out_bf16: torch.Tensor):
         d, s = self.d, self.store
-        ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, s.gview("mask_token").view(-1), partial_ws=w.asm_partial)
+        gmask = s.gview("mask_token").view(-1)
+        handoff = self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") == "1"
+        if self.side is not None and handoff and d.dec_dim % 8 == 0 and d.dec_dim <= 512 and os.environ.get("MOFO_ASM_DEFER", "1") == "1":
+            # d(mask_token) is needed by nothing before the optimizer (or the bucket hand-over, which is issued on the side stream
+            # too): its 24-block reduce goes to the SIDE stream.  On the main stream it sat in the dependent chain behind a CU-filling
+            # weight-gradient launch and took ~180 us for 27 us of work (profiles/r02_rocprof_kernel_stats.csv).
+            ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, None, partial_ws=w.asm_partial)
+            side, ev = self.side, self._asm_ready
+            self._side_launched = True
+            ops.host_op(lambda: ev.record(torch.cuda.current_stream()))
+            ops.use_stream(side)
+            ops.host_op(lambda: side.wait_event(ev))
+            ops.assemble_bwd_finalize(w.asm_partial, w.B, w.N, gmask)
+            ops.use_stream(None)
+        else:
+            ops.assemble_bwd(dx_full.view(w.B, w.N, d.dec_dim), w.n_vis, w.d_e2d, gmask, partial_ws=w.asm_partial)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, w.d_e2d, s.bview("encoder_to_decoder.weight"), w.d_encout)
         self._wgrad(w.d_e2d, enc_out_bf16, s.g2d("encoder_to_decoder.weight"))
         return w.d_encout

@@ -812,6 +812,14 @@ def test_assemble_fwd_bwd(dev):
         assert _rel(dt - 1.0, src[:, nv:].float().sum((0, 1))) < 1e-5
     with pytest.raises(ValueError):
         ops.assemble_bwd(dx, nv, de, dt, partial_ws=ws[:-1])
+    # the deferred form (what the runtime uses: the reduce of d(mask_token) runs later, on the side stream)
+    if D % 8 == 0 and D <= 512:
+        for src in (dx, dxh):
+            de.zero_(), dt.fill_(2.0), ws.fill_(float("nan"))
+            ops.assemble_bwd(src, nv, de, None, partial_ws=ws)
+            assert torch.equal(de.view(Bc, nv, D), src[:, :nv].to(BF16)) and torch.all(dt == 2.0)
+            ops.assemble_bwd_finalize(ws, Bc, N, dt)
+            assert _rel(dt - 2.0, src[:, nv:].float().sum((0, 1))) < 1e-5
 
 
 @pytest.mark.parametrize("cfgname,normalize", [("TINY", True), ("VIT_B", True), ("VIT_B", False)])
