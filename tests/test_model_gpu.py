@@ -890,6 +890,45 @@ def test_vit_large_32_frames_parity(dev):
         assert _rel(g[n], grads[n]) < 6e-2, n
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_vit_large_32_frames_full_depth(dev, monkeypatch, fp8):
+    """SURVEY.md 8c fixture F6: the WHOLE BASELINE configs[4] model -- pretrain_videomae_large_patch16_224 (24 encoder blocks of
+    1024 x 16 heads, modeling_pretrain.py:316-338) with the 4-block 512-wide decoder, one 32 x 224 x 224 clip, tube mask 0.9 --
+    against the reference classes' own forward / backward (tests/golden/vitl32_full.npz, tools/make_goldens.py --only-l32 --full):
+    loss 1e-3 (bf16; 1e-2 with the e4m3 forward Linears, the stated fp8 tolerance), gradient norm, every per-tensor gradient norm."""
+    from oracle import pretrain_oracle as O
+    monkeypatch.setenv("MOFO_FP8", "1" if fp8 else "0")
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=24, enc_heads=16, dec_dim=512, dec_depth=4, dec_heads=8)
+    fx = np.load(os.path.join(G, "vitl32_full.npz"))
+    model, _ = _build(cfg, "xavier", dev)
+    assert model.runtime().fp8 == fp8
+    x = O.keyed_clips(1, cfg)
+    np.random.seed(7)
+    mask = torch.from_numpy(O.tube_mask(cfg.grid, 0.9)[None]).bool()
+    assert np.array_equal(mask.numpy().astype(np.uint8), fx["mask"])
+    loss = model.forward_loss(x.to(dev), mask.to(dev))
+    model.runtime().store.zero_grads()
+    loss.backward()
+    gn = float(model.runtime().grad_norm())
+    model.check_status()
+    assert float(loss.detach()) == pytest.approx(float(fx["loss"]), rel=1e-2 if fp8 else 1e-3)
+    assert gn == pytest.approx(float(fx["grad_norm"]), rel=5e-2 if fp8 else 2e-2)
+    w = model.runtime().ws(1, 320)
+    assert _rel(w.pred.view(1, 2816, 1536)[:, :6, :48], fx["out_slice"]) < (6e-2 if fp8 else 3e-2)
+    g = {n: p.grad for n, p in model.named_parameters()}
+    names = [str(s) for s in fx["names"]]
+    assert len(names) == len(g)
+    worst = ("", 0.0)
+    for i, n in enumerate(names):
+        want = fx["grad_stats"][i, 0]
+        if want < 1e-3 * float(fx["grad_norm"]):
+            continue
+        r = abs(float(g[n].double().norm()) - want) / want
+        if r > worst[1]:
+            worst = (n, r)
+    assert worst[1] < (1.5e-1 if fp8 else 6e-2), worst
+
+
 def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
     """BASELINE configs[4] ("ViT-L 32x224x224 ... fp8 MFMA attention/MLP"): MOFO_FP8=1 runs the LayerNorm-fed forward Linears
     (qkv, fc1) on OCP e4m3 operands with per-tensor scales.  Against the reference classes' fp32 fixture (vitl32.npz) and the

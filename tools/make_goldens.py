@@ -123,6 +123,7 @@ def main():
     ap.add_argument("--only-next", action="store_true", help="only the fixtures of the SURVEY 8f 'next' rows (vis.npz, finetune_*.npz)")
     ap.add_argument("--only-bb-engine", action="store_true", help="only engine_vitb_bb.npz: one step of the reference's own train_one_epoch_BB")
     ap.add_argument("--only-l32", action="store_true", help="only vitl32.npz: ViT-L widths at 32 frames (BASELINE config 4 shapes) through the reference classes")
+    ap.add_argument("--full", action="store_true", help="with --only-l32: the FULL ViT-L depth (24 + 4 blocks) -> vitl32_full.npz (SURVEY 8c fixture F6)")
     ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
     ap.add_argument("--only-ckpt", action="store_true", help="only ckpt_tiny.npz: a checkpoint WRITTEN by the reference's utils.save_model after two steps")
     args = ap.parse_args()
@@ -442,7 +443,8 @@ def make_l32(args, ref_mp, ref_mf, O):
     import contextlib
     import io
     from functools import partial as _partial
-    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=3, enc_heads=16, dec_dim=512, dec_depth=1, dec_heads=8)
+    full = getattr(args, "full", False)       # --full: the whole pretrain_videomae_large_patch16_224 depth (modeling_pretrain.py:316-338), dec 4
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=24 if full else 3, enc_heads=16, dec_dim=512, dec_depth=4 if full else 1, dec_heads=8)
     P = O.keyed_params(cfg, "xavier")
     with contextlib.redirect_stdout(io.StringIO()):
         model = ref_mp.PretrainVisionTransformer(
@@ -465,7 +467,7 @@ def make_l32(args, ref_mp, ref_mf, O):
     grads = {k: p.grad.detach() for k, p in model.named_parameters()}
     names, gstat, ghead = tensor_stats(grads)
     gn = float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values())))
-    np.savez_compressed(os.path.join(args.out, "vitl32.npz"), mask=mask.numpy().astype(np.uint8), loss=np.array(loss.item()), grad_norm=np.array(gn),
+    np.savez_compressed(os.path.join(args.out, "vitl32_full.npz" if full else "vitl32.npz"), mask=mask.numpy().astype(np.uint8), loss=np.array(loss.item()), grad_norm=np.array(gn),
                         names=np.array(names), grad_stats=gstat, grad_head=ghead, out_slice=out[:, :6, :48].detach().numpy(),
                         out_sum=np.array(out.detach().double().sum().item()))
     print("vitl32: loss", loss.item(), "grad norm", gn, "out_sum", out.detach().double().sum().item())
