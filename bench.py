@@ -223,6 +223,7 @@ def main():
     # table, picks the dominant kernel class); in the timed region only that dominant class is bracketed.
     full = None
     n_instr = 0
+    t_gpu0 = time.perf_counter()
     for it in range(args.warmup):
         if not args.no_kernel_events and (it >= min(2, args.warmup - 1)) and full is None:
             full = _lib.EventProfiler()          # step 0 is cold (module load, first touch, list recording) and step 1 is
@@ -259,6 +260,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     clips_per_s = B * world * args.steps / dt
+    gpu_phase_s = time.perf_counter() - t_gpu0     # warm-up + instrumented + timed steps: what a GPU-busy sampler can see of this run
     per_step_ms = np.diff(np.array([t0] + step_ends)) * 1e3
     exposed_ms = None
     if getattr(opt, "measure_exposed", False) and opt.exposed_events:
@@ -279,7 +281,8 @@ def main():
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),
                       "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4),
                       "ms_per_step_median": round(float(np.median(per_step_ms)), 3), "rccl_ranks": rccl_ranks, "backend": backend if (world > 1 or force_dp) else None,
-                      "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 3)}}
+                      "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 3),
+                      "gpu_phase_s": round(gpu_phase_s, 2), "timed_s": round(dt, 3)}}
 
     if prof is not None:
         summ = prof.summary()
@@ -308,17 +311,20 @@ def main():
         # (tools/pmc_step.sh; FETCH_SIZE doubled as the guide prescribes for gfx950).  Counters cannot be read from inside the
         # process, so this is a RECORDED figure: it is reported only while the kernel sources are byte-identical to the ones
         # the profile was taken with (sha256 over mofo_amd/csrc), null otherwise.
-        tpath = os.path.join(ROOT, "profiles", "r02_pmc_step_traffic.json")
+        import glob
+        recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_traffic.json")))
+        tpath = recs[-1] if recs else ""               # the newest round's record
+        tname = "profiles/" + os.path.basename(tpath)
         out["roofline"]["traffic_source"] = None
         if args.model == "vitb16" and B == 32 and os.path.exists(tpath):   # recorded for the headline workload only
             try:
                 prof_rec = json.load(open(tpath))
                 rec = prof_rec.get("classes", {}).get(out["roofline"]["kernel"])
                 if prof_rec.get("_meta", {}).get("csrc_sha256") != csrc_sha():
-                    out["roofline"]["traffic_source"] = "stale: profiles/r02_pmc_step_traffic.json was recorded for other kernel sources"
+                    out["roofline"]["traffic_source"] = "stale: %s was recorded for other kernel sources" % tname
                 elif rec:
                     out["roofline"]["traffic"] = round((rec["fetch_MB_per_launch"] + rec["write_MB_per_launch"]) * 1e6)
-                    out["roofline"]["traffic_source"] = "recorded: profiles/r02_pmc_step_traffic.json (csrc sha256 %s)" % csrc_sha()[:12]
+                    out["roofline"]["traffic_source"] = "recorded: %s (csrc sha256 %s)" % (tname, csrc_sha()[:12])
             except Exception:
                 pass
         gem = [warm[k] for k in warm if k[0] == "gemm"]
