@@ -356,7 +356,10 @@ __device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a qu
 // over all 32 gaps needs the S / dP accumulators double-buffered across query tiles, which no longer fits 256 arch VGPRs.  Removed.
 // What the phase stamps (tools/attn_trace.py dkv) show: of ~2 440 cycles per tile and wave, 730 go to writing the next
 // tile to LDS, the barrier and issuing the next global loads; the two 8-MFMA groups take 610 and 850 cycles (256 each alone).
-template <int NW, bool WHOLE, bool U2 = false>
+// FOLD (1: delta, 2: delta and the exp2 argument): see attn_pingpong.h "Vector diet" -- the wave's V fragments are held negated and
+// dP starts at +delta (exact); with 2 the K fragments are held as bf16(-c K) and S starts at +lse2, p = exp2(-S).  The initial values
+// are read from the staged tile straight into the accumulator registers: 32 VALU per tile (fma, sub) and 32 operand registers go.
+template <int NW, bool WHOLE, bool U2 = false, int FOLD = 0>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
@@ -391,6 +394,18 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     for (int ks = 0; ks < 4; ++ks) {
         kf[ks] = *(const bf16x8*)(kp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
         vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
+        if constexpr (FOLD >= 1) {
+            u32x4 vraw = __builtin_bit_cast(u32x4, vf[ks]);
+            vraw ^= u32x4{0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u};        // -V (exact)
+            vf[ks] = __builtin_bit_cast(bf16x8, vraw);
+        }
+        if constexpr (FOLD >= 2) {
+            const u32x4 kraw = __builtin_bit_cast(u32x4, kf[ks]);
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(-c * bf16lo_to_f32(kraw[e]), -c * bf16hi_to_f32(kraw[e]));
+            kf[ks] = __builtin_bit_cast(bf16x8, o);
+        }
     }
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
@@ -497,6 +512,20 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
         const float* Dt = Lt + 32;
         f32x16 s = zero16(), dpv = zero16();
         f32x4 lvs[4];
+        if constexpr (FOLD >= 1) {
+            // accumulators start at +delta (and +lse2): broadcast reads of the tile's 32 + 32 floats straight into the registers
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
+                const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dpv[4 * rg + e] = dv[e];
+                    if constexpr (FOLD >= 2) s[4 * rg + e] = lv[e];
+                }
+                lvs[rg] = lv;
+            }
+        }
         ATTN_STAMP(qt, 0);
         if constexpr (PRELOAD) {
             // all eight row fragments in flight before the first MFMA: hipcc otherwise re-used one fragment register and
@@ -506,8 +535,10 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             for (int ks = 0; ks < 4; ++ks) qa[ks] = row_frag(Qt, ks, lane);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) oa[ks] = row_frag(Ot, ks, lane);
+            if constexpr (FOLD == 0) {
 #pragma unroll
-            for (int rg = 0; rg < 4; ++rg) lvs[rg] = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+                for (int rg = 0; rg < 4; ++rg) lvs[rg] = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], kf[ks], s, 0, 0, 0);
@@ -532,6 +563,17 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             __builtin_amdgcn_sched_barrier(0);
         }
         float p[16], ds[16];
+        if constexpr (FOLD >= 1) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * rg + e;
+                    const float pr = FOLD >= 2 ? fast_exp2(-s[r]) : fast_exp2(s[r] * c - lvs[rg][e]);
+                    p[r] = pr;
+                    ds[r] = pr * dpv[r];         // = -dS: dK accumulates with the opposite sign, returned at the store
+                }
+        } else {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
             f32x4 lv;
@@ -545,6 +587,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
                 p[r] = pr;
                 ds[r] = pr * (dpv[r] - dv[e]);
             }
+        }
         }
         const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
         const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
@@ -619,9 +662,11 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     }
     if (ki >= N) return;
     bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
-    store_T(drow + D, dk0, dk1, scale, hh);
+    store_T(drow + D, dk0, dk1, FOLD >= 1 ? -scale : scale, hh);
     store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
 }
+
+#include "attn_pingpong.h"
 
 // ------------------------------------------------------------------------------------------------ short sequences: ONE backward kernel
 // N <= 160 (the encoder's visible tokens): delta, dQ, dK and dV of one (clip, head) in ONE block of 5 waves, Q / dO / K
@@ -1245,9 +1290,39 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
-#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, false); } else { LAUNCH_KV_(NW, false, true); } } while (0)
-#define LAUNCH_KV_(NW, WH, U2)                                                                                         \
-    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
+    {
+        // ping-pong form (attn_pingpong.h): one block of NW = 5..8 waves per CU, the two waves of a SIMD one section apart.
+        // MOFO_ATTN_DKV_PP = 0: off, 1: on, 2: on with the exp2 argument folded into the K fragments / S accumulator (read per call).
+        const char* e = getenv("MOFO_ATTN_DKV_PP");
+        const int mode = e ? atoi(e) : 0;
+        if (mode > 0 && N > 160) {
+            const int T = ceil_div(N, 32);
+            int nw = 8, best = 1 << 30;
+            for (int w = 8; w >= 5; --w) {
+                const int pad = ceil_div(T, w) * w - T;
+                if (pad < best) best = pad, nw = w;
+            }
+            const int nxb = ceil_div(T, nw);
+            const dim3 grid(8 * ceil_div(B * H, 8) * nxb);
+#define LAUNCH_PP(NW, F) hipLaunchKernelGGL((attn_dkv_pp_kernel<NW, F>), grid, dim3(NW * 64), 0, s, (const bf16_t*)qkv, ldqkv, nxb, B * H, N, H, c, scale, \
+                                            (const bf16_t*)dout, lddo, (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
+#define LAUNCH_PPF(NW) do { if (mode >= 2) LAUNCH_PP(NW, true); else LAUNCH_PP(NW, false); } while (0)
+            switch (nw) {
+                case 8: LAUNCH_PPF(8); break;
+                case 7: LAUNCH_PPF(7); break;
+                case 6: LAUNCH_PPF(6); break;
+                default: LAUNCH_PPF(5); break;
+            }
+            MOFO_CHECK_LAUNCH("mofo_attention_bwd_dkv(pp)");
+            return MOFO_OK;
+        }
+    }
+    const char* ef = getenv("MOFO_ATTN_DKV_FOLD");      // read per call (A/B in one process): 0 = off, 1 = delta, 2 = delta + exp2 argument
+    const int fold = ef ? atoi(ef) : 2;                 // same-process A/B at the decoder shape: 254.3 / 246.0 / 237.1 us (profiles/r03_attn_dkv_ab.txt)
+#define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, false, 0); } else if (fold >= 2) { LAUNCH_KV_(NW, false, true, 2); } \
+                           else if (fold == 1) { LAUNCH_KV_(NW, false, true, 1); } else { LAUNCH_KV_(NW, false, true, 0); } } while (0)
+#define LAUNCH_KV_(NW, WH, U2, FO)                                                                                     \
+    hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, U2, FO>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
                        (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv, attn_stagger())
     switch (pick_nw(N)) {

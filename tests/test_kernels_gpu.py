@@ -617,7 +617,36 @@ def test_attention_bwd_split_entries(dev):
     ops.attention_delta_zero_dq(out, dout, B, N, H, d3, one)
     assert torch.equal(d3, delta) and float(one[:, :D].abs().max()) == 0.0
     ops.attention_bwd_onepass(qkv, dout, lse2, d3, B, N, H, 0.125, one)
-    assert _rel(one[:, :D], got[:, :D]) < 8e-3 and _rel(one[:, D:], got[:, D:]) < 4e-3
+    # two HIP forms against each other (both are within 2e-2 of fp32 torch in their own tests).  The two-pass dK/dV kernel holds its
+    # K fragments as bf16(-c K) (MOFO_ATTN_DKV_FOLD=2, the default): one more bf16 rounding than the one-pass form -> 6e-3 instead of 4e-3
+    assert _rel(one[:, :D], got[:, :D]) < 8e-3 and _rel(one[:, D:], got[:, D:]) < 6e-3
+
+
+@pytest.mark.parametrize("switch,val", [("MOFO_ATTN_DKV_FOLD", "0"), ("MOFO_ATTN_DKV_FOLD", "1"), ("MOFO_ATTN_DKV_PP", "1"), ("MOFO_ATTN_DKV_PP", "2")])
+@pytest.mark.parametrize("B,N,H", [(1, 1568, 2), (2, 500, 1), (1, 3136, 1), (3, 190, 2)])
+def test_attention_dkv_variants(dev, monkeypatch, switch, val, B, N, H):
+    """the dK/dV pass in its other forms -- accumulator-start folds off / delta only (the default folds both), and the 7/8-wave
+    ping-pong kernel (attn_pingpong.h; measured slower than the 4-wave kernel, kept opt-in) -- against fp32 torch, ragged last
+    tiles and blocks included"""
+    from mofo_amd import ops
+    monkeypatch.setenv(switch, val)
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _rand((B * N, 3 * D), dev, 11, 1.5)
+    out = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(x, B, N, H, scale)
+    dout = _rand((B * N, D), dev, 12)
+    ref.backward(dout.float())
+    dqkv = torch.full_like(qkv, 3.0)
+    delta = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_delta(out, dout, B, N, H, delta)
+    ops.attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv)
+    assert torch.all(dqkv[:, :D] == 3.0)                       # the q third belongs to the dQ pass
+    for name, sl in (("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(dqkv[:, sl], x.grad[:, sl]) < 2e-2, name
 
 
 def test_attention_spiky_softmax(dev):
