@@ -119,6 +119,10 @@ SETS = {
               ("4096^3 NN bf16", NN, E.EPI_BF16, 4096, 4096, 4096, 1), ("4096^3 TN f32", TN, E.EPI_F32, 4096, 4096, 4096, 1),
               ("8192^2 x 4096 NT", NT, E.EPI_BF16, 8192, 8192, 4096, 1), ("4096^2 x 16384 NT", NT, E.EPI_BF16, 4096, 4096, 16384, 1),
               ("16384x4096x4096 NT", NT, E.EPI_BF16, 16384, 4096, 4096, 1), ("8192^3 NN bf16", NN, E.EPI_BF16, 8192, 8192, 8192, 1)],
+    "layout": [("4096^3 NT bf16", NT, E.EPI_BF16, 4096, 4096, 4096, 1), ("4096^3 NT f32", NT, E.EPI_F32, 4096, 4096, 4096, 1),
+               ("4096^3 NN bf16", NN, E.EPI_BF16, 4096, 4096, 4096, 1), ("4096^3 TN f32", TN, E.EPI_F32, 4096, 4096, 4096, 1),
+               ("2304x768x20480 TN", TN, E.EPI_F32, 2304, 768, 20480, 1), ("3072x3072x20480 TN", TN, E.EPI_F32, 3072, 3072, 20480, 1),
+               ("3072x3072x20480 NT", NT, E.EPI_F32, 3072, 3072, 20480, 1)],
     "model": [
         ("enc qkv   NT bf16", NT, E.EPI_BF16, 5120, 2304, 768, 1),
         ("enc fc1   NT gelu", NT, E.EPI_BIAS_GELU, 5120, 3072, 768, 1),
