@@ -78,7 +78,7 @@ int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* w, co
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
 /* the same, and the normalised rows ALSO as OCP e4m3 (y_e4m3 [M, ldy8] = sat(y * qscale[0])): the A operand of the fp8 forward
- * GEMMs (MOFO_GEMM_NT_FP8).  amax_out collects max|y| over a sample of the rows (atomic max) for the caller's next scale. */
+ * GEMMs (MOFO_GEMM_NT_FP8).  amax_out collects max|y| over all rows (atomic max; the caller zeroes it) for the caller's next scale. */
 int mofo_layernorm_fwd_q(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
                          int rows_in, int rows_out, int row_off, void* y_bf16, int ldy, float* mean, float* rstd,
                          void* y_e4m3, int ldy8, const float* qscale, float* amax_out, void* stream);
@@ -90,7 +90,7 @@ int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf
                        int rows_in, int rows_out, int row_off,
                        float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db,
                        const void* dres_bf16, int lddres_bf16,
-                       float* partial_ws /* >= 2*1024*D floats of scratch, or NULL: NULL falls back to contended atomics */,
+                       float* partial_ws /* >= 2 * mofo_layernorm_bwd_blocks(M) * D floats of scratch (2*1024*D always suffices), or NULL: NULL falls back to contended atomics */,
                        void* stream);
 /* Deferred reduction: called with dw = db = NULL (and a partial_ws of its own) mofo_layernorm_bwd leaves only the
  * mofo_layernorm_bwd_blocks(M) block partials in partial_ws; mofo_layernorm_bwd_finalize adds the partials of up to 40

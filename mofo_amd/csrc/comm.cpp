@@ -34,11 +34,22 @@ Api* api() {
     static bool tried = false;
     if (!tried) {
         tried = true;
+        // An RCCL that the process has ALREADY loaded (torch's) is reused: first the global scope, then RTLD_NOLOAD by name; only a
+        // process without one maps the system library -- locally (no RTLD_GLOBAL: its symbols must not interpose on another copy).
         void* h = nullptr;
         const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            h = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (h) break;
+        if (dlsym(RTLD_DEFAULT, "ncclAllReduce")) h = dlopen(nullptr, RTLD_NOW);
+        for (int pass = 0; pass < 2 && !h; ++pass)
+            for (const char* n : names) {
+                h = dlopen(n, RTLD_NOW | RTLD_LOCAL | (pass == 0 ? RTLD_NOLOAD : 0));
+                if (h) break;
+            }
+        if (h) {
+            // the unique id is passed by value as 128 bytes and the enums are restated above: refuse a library whose major
+            // version is not the 2.x ABI they were taken from
+            int (*GetVersion)(int*) = (int (*)(int*))dlsym(h, "ncclGetVersion");
+            int ver = 0;
+            if (!GetVersion || GetVersion(&ver) != ncclSuccess || ver < 20000 || ver >= 30000) h = nullptr;
         }
         if (h) {
             a.GetUniqueId = (int (*)(ncclUniqueId*))dlsym(h, "ncclGetUniqueId");

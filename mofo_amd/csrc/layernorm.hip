@@ -14,8 +14,9 @@ __device__ __forceinline__ size_t map_row(int r, int rows_in, int rows_out, int 
 
 // XB: the residual stream is bf16 (the decoder, runtime.py) instead of f32: 8-byte loads of four elements per lane.
 // Q8: the normalised row also goes out as OCP e4m3 (the A operand of the fp8 forward GEMMs, gemm.hip NT_FP8), multiplied by
-// qscale[0]; every 64th block reports its rows' |y| maximum to amax_out (delayed scaling: enough of a sample to set the
-// NEXT step's scale -- one atomic per block on a single address would cost more than the LayerNorm itself).
+// qscale[0]; the maximum |y| over ALL rows goes to amax_out (delayed scaling: it sets the NEXT step's scale).  The running maximum
+// is read before the atomic, so only the waves that raise it issue one (an atomic per block on one address would cost more than the
+// LayerNorm itself; round 2 sampled every 64th block instead and could miss outlier rows).
 template <int NIT, bool XB, bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv_, int ldx, const float* __restrict__ w,
                                                       const float* __restrict__ b, float eps, int M, int D, int rows_in,
@@ -86,10 +87,11 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
         }
     }
     if constexpr (Q8) {
-        if ((blockIdx.x & 63) == 0) {
-            am = wave_max(am);
-            if (lane == 0) atomicMax((unsigned*)amax_out, __float_as_uint(am));
-        }
+        // EVERY row contributes to the next step's scale (a sample of the rows can miss the few outlier rows a ViT's LayerNorm
+        // outputs have, and values beyond the scale are silently clamped to +-448).  The running maximum is read first: once the
+        // first rows have set it, almost no wave issues the atomic (a stale read only costs a redundant atomic).
+        am = wave_max(am);
+        if (lane == 0 && am > *(volatile const float*)amax_out) atomicMax((unsigned*)amax_out, __float_as_uint(am));
     }
 }
 

@@ -79,15 +79,20 @@ class DeviceTubeMaskingGenerator(_TubeGeometry):
         mask = gen(batch_size, out=model.input_buffers(batch_size, n_vis)[1])     # uint8 [B, 1568] on the device, 1 = masked
     """
 
-    def __init__(self, input_size, mask_ratio, seed=0):
+    def __init__(self, input_size, mask_ratio, seed=0, rank=0, world_size=1):
+        """``rank`` / ``world_size`` (data parallelism): the clip counter of a draw is ``step * global_batch + rank * batch_size + i``,
+        so ranks that share one ``seed`` still draw DIFFERENT masks (the reference's workers are seeded ``seed + rank``,
+        run_mae_pretraining.py:166) and a job's masks do not depend on how its global batch is split over ranks."""
         super().__init__(input_size, mask_ratio)
         self.seed, self.clips_drawn = int(seed), 0
+        self.rank, self.world_size = int(rank), max(1, int(world_size))
 
     def __call__(self, batch_size, out=None, device=None):
         import torch
         from . import ops
         if out is None:
             out = torch.empty(batch_size, self.total_patches, dtype=torch.uint8, device=device or "cuda")
-        ops.tube_masks(self.seed, self.clips_drawn, self.frames, self.num_patches_per_frame, self.num_masks_per_frame, out)
+        counter = self.clips_drawn * self.world_size + self.rank * batch_size     # global index of this rank's first clip of the step
+        ops.tube_masks(self.seed, counter, self.frames, self.num_patches_per_frame, self.num_masks_per_frame, out)
         self.clips_drawn += batch_size
         return out

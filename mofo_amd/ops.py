@@ -270,6 +270,11 @@ def fp8_update_scales(amax, scales, margin=1.5):
     _run("mofo_fp8_update_scales", ("fp8_scales",), 12.0 * n, _p(amax), _p(scales), n, float(margin))
 
 
+def layernorm_bwd_blocks(M):
+    """block rows a LayerNorm backward over M rows leaves in its partial_ws"""
+    return _lib.load().mofo_layernorm_bwd_blocks(int(M))
+
+
 def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):
     """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
     (bf16) are the outputs, either may be None but not both."""
@@ -310,8 +315,8 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         raise ValueError("layernorm_bwd: row map exceeds x")
     if partial_ws is not None:
         _chk(partial_ws, F32, "partial_ws", 1)
-        if partial_ws.numel() < 2 * 1024 * D:
-            raise ValueError("partial_ws must hold 2*1024*D floats")
+        if partial_ws.numel() < 2 * layernorm_bwd_blocks(M) * D:      # [blocks][2][D]; at most 1024 blocks
+            raise ValueError("partial_ws must hold 2 * layernorm_bwd_blocks(M) * D floats (2*1024*D always suffices)")
     xb = 1 if x.dtype == BF16 else 0
     bytes_ = ((4.0 if xb else 6.0) + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
               + (2.0 if dxb is not None else 0.0)) * M * D

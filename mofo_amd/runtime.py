@@ -346,8 +346,12 @@ class PretrainRuntime:
             self._ln_flush()
         D = x.shape[1]
         k = len(self._ln_pending)
+        M = kw.get("M") or dy.shape[0]
+        need = 2 * ops.layernorm_bwd_blocks(M) * D      # what THIS LayerNorm's block partials take (an encoder one: 640 of the 1024 block rows)
         if k >= len(self._ln_pool):
-            self._ln_pool.append(torch.empty(2 * 1024 * self._ln_dmax, dtype=F32, device=self.dev))
+            self._ln_pool.append(torch.empty(need, dtype=F32, device=self.dev))
+        elif self._ln_pool[k].numel() < need:
+            self._ln_pool[k] = torch.empty(need, dtype=F32, device=self.dev)
         ws = self._ln_pool[k]
         nb = ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, None, None, partial_ws=ws, **kw)
         self._ln_pending.append((ws, nb, D, gw, gb))

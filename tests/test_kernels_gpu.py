@@ -153,7 +153,7 @@ def test_fp8_quantisation_kernels(dev):
     ops.layernorm_fwd(xs, w, b, 1e-6, y2, mean, rstd)
     assert torch.equal(y, y2)
     assert torch.equal(y8.view(torch.uint8), (y.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))
-    assert 0.0 < float(am) <= float(y.float().abs().max())              # a sample of the rows
+    assert float(am) == float(y.float().abs().max())                    # every row contributes
     # delayed scaling update
     amx = torch.tensor([2.0, 0.0], dtype=F32, device=dev)
     scales = torch.tensor([[16.0, 1 / 16.0], [8.0, 0.125]], dtype=F32, device=dev)
