@@ -78,7 +78,9 @@ int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const float* w, co
                        int rows_in, int rows_out, int row_off,
                        void* y_bf16, int ldy, float* mean, float* rstd, void* stream);
 /* the same, and the normalised rows ALSO as OCP e4m3 (y_e4m3 [M, ldy8] = sat(y * qscale[0])): the A operand of the fp8 forward
- * GEMMs (MOFO_GEMM_NT_FP8).  amax_out collects max|y| over all rows (atomic max; the caller zeroes it) for the caller's next scale. */
+ * GEMMs (MOFO_GEMM_NT_FP8).  amax_out = MOFO_FP8_AMAX_STRIPES floats (zeroed by the caller / by mofo_fp8_update_scales): max|y| over ALL rows, the
+ * blocks' atomic maxima spread over the stripes; mofo_fp8_update_scales folds them into the next step's scale. */
+#define MOFO_FP8_AMAX_STRIPES 1024
 int mofo_layernorm_fwd_q(const void* x, int x_is_bf16, int ldx, const float* w, const float* b, float eps, int M, int D,
                          int rows_in, int rows_out, int row_off, void* y_bf16, int ldy, float* mean, float* rstd,
                          void* y_e4m3, int ldy8, const float* qscale, float* amax_out, void* stream);
@@ -149,7 +151,8 @@ int mofo_fp8_quantize_segments(const void* x_bf16, long long n, const short* chu
                                void* out_e4m3, float* scale_inv, void* stream);
 /* out = sat_e4m3(x * scale[0]) for a plain bf16 tensor; amax_out (or NULL) collects max|x| by atomic max */
 int mofo_fp8_quantize_bf16(const void* x_bf16, long long n, const float* scale, void* out_e4m3, float* amax_out, void* stream);
-/* delayed scaling: scales[2i] = 448 / (amax[i] * margin), scales[2i+1] = its inverse; amax[i] is cleared.  amax[i] == 0 keeps the old pair */
+/* delayed scaling: a_i = max over amax[i][0 .. MOFO_FP8_AMAX_STRIPES); scales[2i] = 448 / (a_i * margin), scales[2i+1] = its inverse;
+ * the stripes are cleared.  a_i == 0 keeps the old pair */
 int mofo_fp8_update_scales(float* amax, float* scales, int n, float margin, void* stream);
 
 /* ---- masks -> index lists: replaces the boolean gathers x[~mask] / pos[mask] of modeling_pretrain.py:90,261-262

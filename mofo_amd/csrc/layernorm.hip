@@ -14,7 +14,7 @@ __device__ __forceinline__ size_t map_row(int r, int rows_in, int rows_out, int 
 
 // XB: the residual stream is bf16 (the decoder, runtime.py) instead of f32: 8-byte loads of four elements per lane.
 // Q8: the normalised row also goes out as OCP e4m3 (the A operand of the fp8 forward GEMMs, gemm.hip NT_FP8), multiplied by
-// qscale[0]; the maximum |y| over ALL rows goes to amax_out (delayed scaling: it sets the NEXT step's scale).  The running maximum
+// qscale[0]; the maximum |y| over ALL rows goes to amax_out's 1024 stripes (delayed scaling: it sets the NEXT step's scale).  The running maximum
 // is read before the atomic, so only the waves that raise it issue one (an atomic per block on one address would cost more than the
 // LayerNorm itself; round 2 sampled every 64th block instead and could miss outlier rows).
 template <int NIT, bool XB, bool Q8 = false>
@@ -90,8 +90,12 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
         // EVERY row contributes to the next step's scale (a sample of the rows can miss the few outlier rows a ViT's LayerNorm
         // outputs have, and values beyond the scale are silently clamped to +-448).  The running maximum is read first: once the
         // first rows have set it, almost no wave issues the atomic (a stale read only costs a redundant atomic).
+        // amax_out is MOFO_FP8_AMAX_STRIPES (1024) floats: the row waves spread over the stripes (same-address atomics serialise at
+        // ~0.1-0.3 us each, and the thousands of waves that start together all read a zero maximum: with 64 stripes a 10 240-row
+        // LayerNorm took 60 instead of 16 us), mofo_fp8_update_scales folds the stripes
         am = wave_max(am);
-        if (lane == 0 && am > *(volatile const float*)amax_out) atomicMax((unsigned*)amax_out, __float_as_uint(am));
+        float* slot = amax_out + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MOFO_FP8_AMAX_STRIPES - 1));
+        if (lane == 0 && am > *(volatile const float*)slot) atomicMax((unsigned*)slot, __float_as_uint(am));
     }
 }
 

@@ -85,16 +85,21 @@ __global__ __launch_bounds__(256) void quant_bf16_kernel(const bf16_t* __restric
 }
 
 // scales[i] = (448 / (amax[i] * margin), its inverse); amax[i] is cleared for the next step.  A site that saw nothing keeps its scale.
+// amax is [n][MOFO_FP8_AMAX_STRIPES]: one wave per site folds its stripes (the LayerNorm blocks spread their atomics over them)
 __global__ void update_scales_kernel(float* __restrict__ amax, float* __restrict__ scales, int n, float margin) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float a = amax[i];
-    if (a > 0.f && a < 3.0e38f) {
+    const int i = blockIdx.x, lane = threadIdx.x;
+    float* row = amax + (size_t)i * MOFO_FP8_AMAX_STRIPES;
+    float a = 0.f;
+    for (int k = lane; k < MOFO_FP8_AMAX_STRIPES; k += 64) {
+        a = fmaxf(a, row[k]);
+        row[k] = 0.f;
+    }
+    a = wave_max(a);
+    if (lane == 0 && a > 0.f && a < 3.0e38f) {
         const float s = E4M3_MAX / (a * margin);
         scales[2 * i] = s;
         scales[2 * i + 1] = 1.0f / s;
     }
-    amax[i] = 0.f;
 }
 
 }  // namespace
@@ -129,7 +134,7 @@ extern "C" int mofo_fp8_quantize_bf16(const void* x_bf16, long long n, const flo
 
 extern "C" int mofo_fp8_update_scales(float* amax, float* scales, int n, float margin, void* stream) {
     if (!amax || !scales || n <= 0 || !(margin > 0.f)) MOFO_FAIL(MOFO_EINVAL, "mofo_fp8_update_scales: bad arguments");
-    hipLaunchKernelGGL(update_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, scales, n, margin);
+    hipLaunchKernelGGL(update_scales_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, amax, scales, n, margin);
     MOFO_CHECK_LAUNCH("mofo_fp8_update_scales");
     return MOFO_OK;
 }

@@ -227,11 +227,13 @@ def layernorm_fwd(x, w, b, eps, y, mean, rstd, M=None, rows_in=None, rows_out=No
 
 
 def layernorm_fwd_q(x, w, b, eps, y, mean, rstd, y8, qscale, amax_out):
-    """layernorm_fwd that also writes the rows as e4m3 (y8 = sat(y * qscale[0])) and reports a sampled max|y| into amax_out"""
+    """layernorm_fwd that also writes the rows as e4m3 (y8 = sat(y * qscale[0])) and reports max|y| into amax_out's stripes"""
     if x is None or x.dtype not in (F32, BF16):
         raise TypeError("x must be f32 or bf16")
     _chk(x, x.dtype, "x", 2), _chk(w, F32, "w", 1), _chk(b, F32, "b", 1), _chk(y, BF16, "y", 2), _chk(mean, F32, "mean", 1), _chk(rstd, F32, "rstd", 1)
     _chk(y8, F8, "y8", 2), _chk(qscale, F32, "qscale"), _chk(amax_out, F32, "amax_out")
+    if amax_out.numel() != FP8_AMAX_STRIPES or not amax_out.is_contiguous():
+        raise ValueError("layernorm_fwd_q: amax_out must be the %d stripes of one site" % FP8_AMAX_STRIPES)
     M, D = y.shape
     if x.shape != (M, D) or y8.shape != (M, D) or w.numel() != D or b.numel() != D or mean.numel() < M or rstd.numel() < M:
         raise ValueError("layernorm_fwd_q: shape mismatch")
@@ -262,9 +264,14 @@ def fp8_quantize_bf16(x, scale, out8, amax_out=None):
     return out8
 
 
+FP8_AMAX_STRIPES = 1024   # include/mofo_hip.h MOFO_FP8_AMAX_STRIPES
+
+
 def fp8_update_scales(amax, scales, margin=1.5):
-    _chk(amax, F32, "amax", 1), _chk(scales, F32, "scales", 2)
-    n = amax.numel()
+    _chk(amax, F32, "amax", 2), _chk(scales, F32, "scales", 2)
+    if amax.shape[1] != FP8_AMAX_STRIPES or not amax.is_contiguous():
+        raise ValueError("fp8_update_scales: amax must be a contiguous [sites, %d] tensor" % FP8_AMAX_STRIPES)
+    n = amax.shape[0]
     if tuple(scales.shape) != (n, 2) or not scales.is_contiguous():
         raise ValueError("fp8_update_scales: scales must be [n, 2]")
     _run("mofo_fp8_update_scales", ("fp8_scales",), 12.0 * n, _p(amax), _p(scales), n, float(margin))

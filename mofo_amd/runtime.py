@@ -317,7 +317,7 @@ class PretrainRuntime:
                         setattr(W, attr + "_si", store.w_si(n) if n in names else None)
                 nsite = 2 * len(blocks)
                 self.act_scales = torch.tensor([[16.0, 1.0 / 16.0]] * nsite, dtype=F32, device=self.dev)
-                self.act_amax = torch.zeros(nsite, dtype=F32, device=self.dev)
+                self.act_amax = torch.zeros(nsite, ops.FP8_AMAX_STRIPES, dtype=F32, device=self.dev)
                 for i, W in enumerate(blocks):
                     W.site = 2 * i
                 self._fp8_calibrated = False
@@ -480,7 +480,7 @@ class PretrainRuntime:
         f8 = self.fp8 and getattr(W, "qkv8", None) is not None and hasattr(L, "xln1_8")
         if f8:
             sc, am = self.act_scales, self.act_amax
-            ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[W.site, 0:1], am[W.site:W.site + 1])
+            ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[W.site, 0:1], am[W.site])
             ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, L.xln1_8, W.qkv8, L.qkv, bias=W.qkvb, a_scale_inv=sc[W.site, 1:2], b_scale_inv=W.qkv8_si)
         else:
             ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
@@ -491,7 +491,7 @@ class PretrainRuntime:
         else:
             ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
         if f8:
-            ops.layernorm_fwd_q(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2, L.xln2_8, sc[W.site + 1, 0:1], am[W.site + 1:W.site + 2])
+            ops.layernorm_fwd_q(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2, L.xln2_8, sc[W.site + 1, 0:1], am[W.site + 1])
             ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, L.xln2_8, W.fc18, L.h1, C2=L.g, bias=W.fc1b, a_scale_inv=sc[W.site + 1, 1:2],
                      b_scale_inv=W.fc18_si)
         else:

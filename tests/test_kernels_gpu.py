@@ -148,18 +148,19 @@ def test_fp8_quantisation_kernels(dev):
     y2 = torch.empty_like(y)
     mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
     y8 = torch.empty(M, D, dtype=F8, device=dev)
-    am.zero_()
-    ops.layernorm_fwd_q(xs, w, b, 1e-6, y, mean, rstd, y8, sc, am)
+    ams = torch.zeros(ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)     # the row waves' atomic maxima are spread over the stripes
+    ops.layernorm_fwd_q(xs, w, b, 1e-6, y, mean, rstd, y8, sc, ams)
     ops.layernorm_fwd(xs, w, b, 1e-6, y2, mean, rstd)
     assert torch.equal(y, y2)
     assert torch.equal(y8.view(torch.uint8), (y.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))
-    assert float(am) == float(y.float().abs().max())                    # every row contributes
-    # delayed scaling update
-    amx = torch.tensor([2.0, 0.0], dtype=F32, device=dev)
+    assert float(ams.max()) == float(y.float().abs().max())             # EVERY row contributes (an outlier row cannot be missed)
+    # delayed scaling update: a site's stripes are folded, then cleared
+    amx = torch.zeros(2, ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
+    amx[0, 5], amx[0, 700] = 1.5, 2.0
     scales = torch.tensor([[16.0, 1 / 16.0], [8.0, 0.125]], dtype=F32, device=dev)
     ops.fp8_update_scales(amx, scales, margin=1.5)
     assert scales[0, 0].item() == pytest.approx(448.0 / 3.0) and scales[0, 1].item() == pytest.approx(3.0 / 448.0)
-    assert scales[1].tolist() == [8.0, 0.125] and amx.tolist() == [0.0, 0.0]
+    assert scales[1].tolist() == [8.0, 0.125] and float(amx.abs().max()) == 0.0
 
 
 def test_gemm_nt_pos_rowmap(dev):
