@@ -135,6 +135,23 @@ __device__ __forceinline__ bool decode_block(int nx, int G, int H, int& xb, int&
     return true;
 }
 
+// LDS-DMA (global -> LDS, no VGPR destination) as inline asm: invisible to hipcc's wait-count bookkeeping, so the loads of
+// the NEXT query block can stay in flight across the barriers of a whole block (7 steps) and are drained by one explicit
+// `s_waitcnt vmcnt(0)` before the block's last barrier.  Register staging (load at the top of a step, ds_write at its end)
+// made every step as long as a loaded chip's global-load latency: 4 700 clk for 640 clk of MFMA.  M0 = LDS byte address of
+// the wave's 1 KiB (dwordx4) / 256 B (dword) piece; lane l lands at + 16 l / + 4 l; the source address is per lane.
+__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ void dma_b32(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a query row beyond N: p = exp2(-big) = 0, delta = 0
+
 // ------------------------------------------------------------------------------------------------ forward
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
@@ -195,10 +212,20 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         }
     };
     if constexpr (WHOLE) {
-        for (int kt = 0; kt < nkt; ++kt) {
-            gload(kt);
-            lwrite(kt);
+        // all K / V tiles at once by LDS-DMA: nkt x 8 pieces of 8 rows x 128 B, dealt round-robin to the waves, all in flight together
+        // (the register-staged loop paid one global round trip PER TILE before the first MFMA: 5 in a row for the encoder's 160 keys;
+        // the XOR swizzle goes on the per-lane SOURCE chunk, DMA writes are lane-linear)
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned lds0 = (unsigned)(size_t)LDS_PTR(smem);
+        for (int pc = wave_u; pc < nkt * 8; pc += NW) {
+            const int kt = pc >> 3, isv = (pc >> 2) & 1, sub = pc & 3;
+            const int rl = sub * 8 + (lane >> 3);
+            int r = kt * 32 + rl;
+            r = r < N ? r : N - 1;
+            const int ch = (lane & 7) ^ swz(rl);
+            dma_b128((isv ? vp : kp) + (size_t)r * ldqkv + ch * 8, lds0 + (unsigned)(kt * 2 * TILE + isv * TILE + sub * 1024));
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     } else {
         gload(0);
@@ -322,22 +349,6 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     }
 }
 
-// LDS-DMA (global -> LDS, no VGPR destination) as inline asm: invisible to hipcc's wait-count bookkeeping, so the loads of
-// the NEXT query block can stay in flight across the barriers of a whole block (7 steps) and are drained by one explicit
-// `s_waitcnt vmcnt(0)` before the block's last barrier.  Register staging (load at the top of a step, ds_write at its end)
-// made every step as long as a loaded chip's global-load latency: 4 700 clk for 640 clk of MFMA.  M0 = LDS byte address of
-// the wave's 1 KiB (dwordx4) / 256 B (dword) piece; lane l lands at + 16 l / + 4 l; the source address is per lane.
-__device__ __forceinline__ void dma_b128(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void dma_b32(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a query row beyond N: p = exp2(-big) = 0, delta = 0
 
 
 // ------------------------------------------------------------------------------------------------ dK, dV
