@@ -739,55 +739,57 @@ __global__ __launch_bounds__(FUSED_NW * 64) void attn_bwd_fused_kernel(const bf1
     bf16x8 vf[4];
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
-    // ---- stage Q, dO, K tiles; lse2 and delta per query row (all loads of all tiles issued before the first is consumed)
+    // ---- stage the Q, dO, K tiles by LDS-DMA: nt x 12 pieces of 8 rows x 128 B dealt round-robin to the waves, ALL in flight at once
+    // (round 2 staged through registers in two batches: two global round trips plus 15 ds_write passes before the first MFMA --
+    // 41 % of a block's life; the XOR swizzle goes on the per-lane SOURCE chunk, DMA writes are lane-linear)
+    {
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        const unsigned lq = (unsigned)(size_t)LDS_PTR(QT), lo = (unsigned)(size_t)LDS_PTR(OT), lk = (unsigned)(size_t)LDS_PTR(KT);
+        for (int pc = wave_u; pc < nt * 12; pc += FUSED_NW) {
+            const int t = pc / 12, rem = pc - 12 * t, which = rem >> 2, sub = rem & 3;
+            const int rl = sub * 8 + (lane >> 3);
+            int r = t * 32 + rl;
+            r = r < N ? r : N - 1;
+            const int ch = (lane & 7) ^ swz(rl);
+            const bf16_t* src = which == 0 ? qp + (size_t)r * ldqkv : (which == 1 ? dop + (size_t)r * lddo : kp + (size_t)r * ldqkv);
+            dma_b128(src + ch * 8, (which == 0 ? lq : (which == 1 ? lo : lk)) + (unsigned)(t * TILE + sub * 1024));
+        }
+    }
+    // ---- lse2 and delta = rowsum(dO * O) per query row, from registers while the DMA flies (8 lanes per row, 8 columns each)
     if (tid < 256) {
         const int rl = tid >> 3, ch = tid & 7;
-        // two batches (3 + 2 tiles): the loads of a batch are all issued before its first use; 80 staging VGPRs at once
-        // would not fit beside the 3-waves-per-SIMD register budget
+        bf16x8 g[FUSED_NW], o[FUSED_NW];
+        float lv[FUSED_NW];
 #pragma unroll
-        for (int t0 = 0; t0 < FUSED_NW; t0 += 3) {
-            constexpr int NB = 3;
-            u32x4 q[NB], k[NB];
-            bf16x8 g[NB], o[NB];
-            float lv[NB];
-#pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int t = t0 + u;
-                if (t < nt && t < FUSED_NW) {
-                    const int row = t * 32 + rl;
-                    const int r = row < N ? row : N - 1;
-                    q[u] = *(const u32x4*)(qp + (size_t)r * ldqkv + ch * 8);
-                    k[u] = *(const u32x4*)(kp + (size_t)r * ldqkv + ch * 8);
-                    g[u] = *(const bf16x8*)(dop + (size_t)r * lddo + ch * 8);
-                    o[u] = *(const bf16x8*)(op + (size_t)r * ldo + ch * 8);
-                    lv[u] = lp[r];
-                }
+        for (int t = 0; t < FUSED_NW; ++t) {
+            if (t < nt) {
+                const int row = t * 32 + rl;
+                const int r = row < N ? row : N - 1;
+                g[t] = *(const bf16x8*)(dop + (size_t)r * lddo + ch * 8);
+                o[t] = *(const bf16x8*)(op + (size_t)r * ldo + ch * 8);
+                lv[t] = lp[r];
             }
+        }
 #pragma unroll
-            for (int u = 0; u < NB; ++u) {
-                const int t = t0 + u;
-                if (t < nt && t < FUSED_NW) {
-                    const int row = t * 32 + rl;
-                    const int off = t * TILE + rl * RS + ((ch ^ swz(rl)) << 4);
-                    *(u32x4*)(QT + off) = q[u];
-                    *(u32x4*)(KT + off) = k[u];
-                    *(bf16x8*)(OT + off) = g[u];
-                    float part = 0.f;
+        for (int t = 0; t < FUSED_NW; ++t) {
+            if (t < nt) {
+                const int row = t * 32 + rl;
+                float part = 0.f;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) part += (float)g[u][j] * (float)o[u][j];
-                    part += __shfl_xor(part, 1, 64);
-                    part += __shfl_xor(part, 2, 64);
-                    part += __shfl_xor(part, 4, 64);
-                    if (ch == 0) {
-                        // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
-                        LD[t * 64 + rl] = row < N ? lv[u] : 1.0e30f;
-                        LD[t * 64 + 32 + rl] = row < N ? part : 0.f;
-                        if (row < N && delta_out) delta_out[((size_t)b * H + h) * N + row] = part;
-                    }
+                for (int j = 0; j < 8; ++j) part += (float)g[t][j] * (float)o[t][j];
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                if (ch == 0) {
+                    // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
+                    LD[t * 64 + rl] = row < N ? lv[t] : 1.0e30f;
+                    LD[t * 64 + 32 + rl] = row < N ? part : 0.f;
+                    if (row < N && delta_out) delta_out[((size_t)b * H + h) * N + row] = part;
                 }
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces have landed; the barrier covers the others'
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16(), q0 = zero16(), q1 = zero16();
     FUSED_STAMP(1);
     __syncthreads();
