@@ -1134,6 +1134,7 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
         for (int i = 0; legal && i < count; ++i) {
             // NT / NN stream whole K-tile PAIRS of a k-contiguous operand: a K-tile past the end would read the next row, not zeros
             if (a[i].op != MOFO_GEMM_TN && (a[i].K % 128 || a[i].splits > 1)) legal = false;
+            if (a[i].colsum) legal = false;      // the fused bias-gradient column sums ride on the 128 x 128 TN kernel only
         }
         if (legal && (mode == 1 || gemm8_wanted(a, count))) mi = 16;
     }

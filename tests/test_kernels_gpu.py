@@ -328,6 +328,14 @@ def test_gemm8_counted_vmcnt_family(dev, monkeypatch, M, N, K):
     Cf.zero_()
     ops.gemm(ops.GEMM_TN, ops.EPI_F32, At, Bt, Cf, splits=2)
     close(Cf, want)
+    # a grouped launch: three weight-gradient problems of different shapes in one grid (per-tile problem lookup, per-problem SRDs)
+    R = K + 8
+    dYs = [_rand((R, p_), dev, 20 + i, 0.1) for i, p_ in enumerate((M, 384, 264))]
+    Xs = [_rand((R, q_), dev, 30 + i, 0.1) for i, q_ in enumerate((N, 136, 512))]
+    Gs = [torch.empty(dy.shape[1], x.shape[1], dtype=F32, device=dev) for dy, x in zip(dYs, Xs)]
+    ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, [(dy, x, g, dict(splits=1, accumulate=False)) for dy, x, g in zip(dYs, Xs, Gs)])
+    for dy, x, g in zip(dYs, Xs, Gs):
+        close(g, dy.float().t() @ x.float())
 
 
 def test_gemm_rejects_bad_shapes(dev):
