@@ -1084,16 +1084,20 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
     MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: op %d with epilogue %d is not built", op, epi);
 }
 
-// Shapes routed to the 256 x 256 kernel by default, from same-process A/B timings on MI355X (tools/gemm8_ab.py,
-// profiles/r03_gemm8_ab.txt): it wins where a block walks several 256 x 256 tiles of a DEEP reduction (8192^3: 1 341-1 377 vs
-// 833-864 TFLOP/s) and loses at every shape of the ViT-B / ViT-L step (K = 384 ... 4096 with 5 120 ... 100 352 token rows:
-// 0.42-0.97 x): one block per CU cannot overlap its (HBM-heavy) epilogue with another block's main loop, and all CUs reach their
-// epilogues together.  DESIGN.md section 4c.
+// Shapes routed to the 256 x 256 kernel by default, from same-process, STEADY-STATE A/B timings on MI355X (tools/gemm8_ab.py,
+// profiles/r03_gemm8_ab.txt; 20 ms of the same variant before every timed block -- in 2-ms bursts the 256-tile kernel reads 20-35 % low):
+//   * any NT / NN problem that gives a block several tiles of a deep reduction: 8192^2 x 4096 1.45 x, 16384 x 4096 x 4096 1.44 x,
+//     8192^3 1.61 x (NN 1.60 x), 4096^2 x 16384 1.12 x; 4096^3 0.98 x
+//   * the forward (NT) GEMMs of the ViT-L / 32-frame step (BASELINE configs[4]: 10 240 encoder and 100 352 decoder rows): enc qkv
+//     1.09 x, proj 1.05 x, fc1 + GELU 1.05 x, fc2 1.13 x, dec qkv 1.23 x, fc2 1.11 x, fc1 + GELU 1.02 x
+//   * not the ViT-B step (5 120 / 50 176 rows, K = 384 / 768, N = 384 / 768 / 1152): 0.47-0.99 x -- too few, too short tiles for
+//     one block per CU, nor the dgrad (NN) GEMMs of ViT-L (0.88-1.03 x), nor weight gradients (tile counts).
 static bool gemm8_wanted(const mofo_gemm_args* a, int count) {
-    if (count != 1 || a[0].op == MOFO_GEMM_TN) return false;
+    if (count != 1 || a[0].op == MOFO_GEMM_TN || a[0].N % 256) return false;
     const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, 256);
-    // measured: 8192^2 x 4096 1.54 x, 16384 x 4096 x 4096 1.34 x, 8192^3 1.59 x (NN 1.65 x), 4096^2 x 16384 1.10 x; 4096^3 0.97 x
-    return a[0].N % 256 == 0 && ((t256 >= 1024 && a[0].K >= 4096) || (t256 >= 256 && a[0].K >= 16384));
+    const int K = a[0].K;
+    if ((t256 >= 1024 && K >= 4096) || (t256 >= 256 && K >= 16384)) return true;
+    return a[0].op == MOFO_GEMM_NT && t256 >= 160 && (K >= 1024 || (K >= 512 && t256 >= 2000));
 }
 
 extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* stream) {
