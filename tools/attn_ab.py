@@ -15,6 +15,8 @@ ap.add_argument("--env", default="MOFO_ATTN_RESCALE_THR")
 ap.add_argument("--vals", default="6")
 ap.add_argument("--rounds", type=int, default=7)
 ap.add_argument("--iters", type=int, default=10)
+ap.add_argument("--warm", type=int, default=80, help="launches of the same variant before every timed block (steady state: short bursts after another "
+                                                     "kernel are timed in a transient -- one-block-per-CU kernels read 20-35 %% low)")
 a = ap.parse_args()
 B, n, H = a.dims
 dev = torch.device("cuda:0")
@@ -65,7 +67,8 @@ for rnd in range(a.rounds + 1):
         for name, lib, fl in variants:
             os.environ[a.env] = fl
             f = kern(lib)[kn]
-            f(); torch.cuda.synchronize()
+            for _ in range(max(1, a.warm)): f()
+            torch.cuda.synchronize()
             e0.record()
             for _ in range(a.iters): f()
             e1.record(); torch.cuda.synchronize()
