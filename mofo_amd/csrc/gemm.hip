@@ -1160,6 +1160,9 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
 extern "C" int mofo_debug_trace_read(void* dst_host, size_t bytes) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
 }
+extern "C" int mofo_debug_trace8_read(void* dst_host, size_t bytes) {
+    return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g8_trace), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
+}
 extern "C" int mofo_debug_trace_it_read(void* dst_host, size_t bytes) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace_it), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
 }

@@ -94,6 +94,18 @@ constexpr int g8_epi_stores() {
          : 55;   // F32: 32 plain stores, or one atomic per row when accumulating (then the wait clamps: over-waiting is safe)
 }
 
+#ifdef MOFO_GEMM_TRACE
+// debug build only (tools/gemm8_trace.py): s_memtime stamps of one K-tile (the 7th of a block's stream), wave 0 (group 0) and wave 4 (group 1)
+__device__ unsigned long long g8_trace[256 * 64];
+#define G8_STAMP(slot)                                                                                                   \
+    do {                                                                                                                 \
+        if (trace_on && (threadIdx.x & 255) == 0 && blockIdx.x < 256)                                                    \
+            g8_trace[blockIdx.x * 64 + (threadIdx.x >> 8) * 32 + (slot)] = __builtin_readcyclecounter();                   \
+    } while (0)
+#else
+#define G8_STAMP(slot)
+#endif
+
 template <int LA, int LB, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[G8_RING + G8_EPB];
@@ -208,6 +220,9 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
             const bool e1 = !o1 || has_next, e2 = !o2 || has_next;
             const bool tail = !e2;                          // last two K-tiles of the stream: nothing younger to leave in flight
             const bool after_epi = (kt == 0) && !first_tile;
+#ifdef MOFO_GEMM_TRACE
+            const bool trace_on = first_tile && kt == 6;
+#endif
             bf16x8 bfr[4][2], af[2][2];
             auto read_a = [&](int q) {
 #pragma unroll
@@ -239,14 +254,22 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
                 dma();
 #endif
             };
+            int ph = 0;
+            (void)ph;
             auto mid = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
+                G8_STAMP(4 * ph + 1);          // load section done (reads and DMA issued, counted wait passed)
                 __builtin_amdgcn_s_barrier();
+                G8_STAMP(4 * ph + 2);          // past the barrier: MFMA section starts
             };
             auto end = [&]() {
                 __builtin_amdgcn_sched_barrier(0);
+                G8_STAMP(4 * ph + 3);          // MFMAs issued
                 __builtin_amdgcn_s_barrier();
+                ++ph;
+                G8_STAMP(4 * ph);              // past the barrier: next load section starts
             };
+            G8_STAMP(0);
             constexpr int SE = g8_epi_stores<EPI>();
 #if G8_DMA_IN_M
             // slots (issued inside the MFMA cluster: a half may be restaged ONE phase after its last reading phase):
