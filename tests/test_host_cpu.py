@@ -180,6 +180,15 @@ def test_flat_store_layout_and_views():
     assert st.grads_attached()
 
 
+def test_weight_gradient_group_size_by_shape():
+    """encoder blocks per grouped weight-gradient launch = the smallest group that fills whole rounds of the 768 resident 128 x 128
+    tiles best: ViT-B (432 tiles per block) takes three blocks per launch, ViT-L (768 = one round exactly) one"""
+    from mofo_amd.runtime import _pick_wgrad_blocks
+    assert _pick_wgrad_blocks(768, 3072) == 3
+    assert _pick_wgrad_blocks(1024, 4096) == 1
+    assert _pick_wgrad_blocks(128, 512) in (1, 2, 3)
+
+
 def test_gradient_segments_tile_the_buffer():
     model = _tiny_model()
     rt, st = _cpu_runtime(model)

@@ -700,6 +700,13 @@ def test_device_tube_masks(dev, grid, ratio):
     assert np.array_equal(again, got)                                             # deterministic in (seed, clip counter)
     other = DeviceTubeMaskingGenerator(grid, ratio, seed=124)(7, device=dev).cpu().numpy()
     assert P < 100 or not np.array_equal(other, got)
+    # data parallelism: ranks that share a seed draw DIFFERENT clips, and the job's masks do not depend on how the global batch is
+    # split -- rank r of w takes clips [r*b, (r+1)*b) of every step's global batch of w*b clips
+    g0, g1 = DeviceTubeMaskingGenerator(grid, ratio, seed=123, rank=0, world_size=2), DeviceTubeMaskingGenerator(grid, ratio, seed=123, rank=1, world_size=2)
+    steps = [np.concatenate([g0(3, device=dev).cpu().numpy(), g1(3, device=dev).cpu().numpy()]) for _ in range(2)]
+    one = DeviceTubeMaskingGenerator(grid, ratio, seed=123)
+    assert all(np.array_equal(st_, one(6, device=dev).cpu().numpy()) for st_ in steps)
+    assert P < 100 or not np.array_equal(steps[0][:3], steps[0][3:])
     # the index lists of such a mask
     nv = F * (P - gen.num_masks_per_frame)
     vis = torch.empty(7, nv, dtype=torch.int32, device=dev)
