@@ -1,3 +1,6 @@
+"""Grouped weight gradients (TN, f32 out) of 1-4 encoder blocks per launch through the 128 x 128 kernel and through gemm8, steady state
+(GPU box only).  Four blocks = 16 problems need MAXG >= 16 in csrc/gemm.hip (13 in the tree): that row is skipped otherwise.
+usage: wgrad_group_gemm8.py [token_rows D]"""
 import os, sys, statistics, torch
 sys.path.insert(0, os.getcwd())
 from mofo_amd import ops
@@ -21,6 +24,10 @@ for nb in (1, 2, 3, 4):
     row = [f"{nb} block(s):"]
     for mode in ("0", "1"):
         os.environ["MOFO_GEMM8"] = mode
-        us = t(lambda: ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs), 60, 20)
+        try:
+            us = t(lambda: ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs), 60, 20)
+        except RuntimeError as e:
+            row.append(f"gemm8={mode} refused ({str(e)[-40:]}) |")
+            continue
         row.append(f"gemm8={mode} {us:7.1f} us = {us / nb:6.1f} per block, {flop_block * nb / us / 1e6:5.0f} TF/s |")
     print(" ".join(row))
