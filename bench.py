@@ -239,6 +239,20 @@ def main():
         dom_key = max(fs, key=lambda k: fs[k]["ms"])
         prof = _lib.EventProfiler(only=dom_key)
         _lib.PROFILER = prof
+    # Self-check of the overlapped gradient exchange (first N > 1 RCCL run: the only place the side-stream hand-off of
+    # runtime._seg_now can be value-checked): the all-reduced gradients of the production path against a fully synchronised
+    # all-reduce of a saved copy, same inputs, no optimizer step in between (dist.GradSync.value_check).
+    ar_check = None
+    if world > 1 or force_dp:
+        def _bwd_only():
+            loss_ = wrapped.forward_loss(clips, mask_dev, True)
+            opt.zero_grad()
+            loss_.backward()
+        ar_check = wrapped.sync.value_check(_bwd_only)
+        opt.zero_grad()
+        if rank == 0:
+            print(f"[bench] all-reduce value check: {'ok' if ar_check['ok'] else 'FAIL'} (max relative error {ar_check['max_rel']:.2e} over "
+                  f"{ar_check['ranges']} ranges, worst {ar_check['worst_range']})", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -262,15 +276,21 @@ def main():
     clips_per_s = B * world * args.steps / dt
     gpu_phase_s = time.perf_counter() - t_gpu0     # warm-up + instrumented + timed steps: what a GPU-busy sampler can see of this run
     per_step_ms = np.diff(np.array([t0] + step_ends)) * 1e3
-    exposed_ms = None
+    exposed_ms, exposed_per_rank = None, None
     if getattr(opt, "measure_exposed", False) and opt.exposed_events:
         # time the compute stream spent waiting for gradient exchanges that had not finished when the optimizer reached them
         ex = [sum(a.elapsed_time(b) for a, b in ev) for ev in opt.exposed_events]
         exposed_ms = float(np.median(ex))
+        exposed_per_rank = [round(exposed_ms, 3)]
         if world > 1:
-            t = torch.tensor([exposed_ms], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            exposed_ms = float(t.item())
+            t = torch.zeros(world, dtype=torch.float64, device=dev)
+            t[rank] = exposed_ms
+            dist.all_reduce(t)                       # every rank's median, rank by rank
+            exposed_per_rank = [round(float(x), 3) for x in t.tolist()]
+            exposed_ms = max(exposed_per_rank)
+            if rank == 0:
+                print("[bench] exposed all-reduce wait per rank (ms, median over steps): " + " ".join(f"{x:.3f}" for x in exposed_per_rank),
+                      file=sys.stderr, flush=True)
 
     out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step" if args.model == "vitb16" else "clips/sec (32x3x224x224, mask 90%) ViT-L pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
@@ -282,6 +302,9 @@ def main():
                       "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4),
                       "ms_per_step_median": round(float(np.median(per_step_ms)), 3), "rccl_ranks": rccl_ranks, "backend": backend if (world > 1 or force_dp) else None,
                       "exposed_allreduce_ms": None if exposed_ms is None else round(exposed_ms, 3),
+                      "exposed_allreduce_ms_per_rank": exposed_per_rank,
+                      "allreduce_value_check": None if ar_check is None else ("ok" if ar_check["ok"] else "fail"),
+                      "allreduce_value_check_max_rel": None if ar_check is None else float("%.3e" % ar_check["max_rel"]),
                       "gpu_phase_s": round(gpu_phase_s, 2), "timed_s": round(dt, 3)}}
 
     if prof is not None:

@@ -66,6 +66,10 @@ int mofo_gemm(const mofo_gemm_args* args, void* stream);
 /* up to 13 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of three transformer blocks
  * and the patch embed's) */
 int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
+/* Diagnostics (host side, no device work): launches per main-loop family since the last reset -- out[0] one tile per block,
+ * [1] persistent 64/128-row tiles, [2] persistent 256-row tiles, [3] in-block split-K, [4] the 256 x 256 counted-vmcnt kernel,
+ * [5] e4m3, [6..7] reserved.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
+int mofo_gemm_route_counts(long long* out, int n, int reset);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */
 int mofo_colsum_bf16(const void* X, int ldx, int M, int N, float* out, void* stream);   /* out must be zeroed */
@@ -237,8 +241,11 @@ int mofo_sumsq(const float* g, long long n, float* partial, float* out_norm, voi
 int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out, void* stream);
-/* mofo_adamw behind a device-side gate: the kernel leaves p, m, v and p_bf16 untouched (and norm_partial unwritten) unless
- * gate_finite[0] is finite, gate_zero[0] == 0 and gate_one[0] == 1.0f (each pointer may be NULL = not checked).  The host enqueues
+/* mofo_adamw behind a device-side gate: the kernel leaves p, m, v and p_bf16 untouched unless gate_finite[0] is finite,
+ * gate_zero[0] == 0 and gate_one[0] == 1.0f (each pointer may be NULL = not checked).  A skipped update writes NaN into its
+ * norm_partial slots, so the norm reduced behind it (norm_out / mofo_norm_finalize) reads NaN, never a previous step's value.
+ * The gate reflects the LAST forward only, and the caller's step counter (bias correction) is the caller's business: the drop-in
+ * engine aborts on the non-finite loss it reads right after (engine_for_pretraining.py:168-170), as the reference does.  The host enqueues
  * backward and the update before it reads the loss; the reference stops before backward on a non-finite loss
  * (engine_for_pretraining.py:168-176), so a bad step must not reach the parameters. */
 int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,

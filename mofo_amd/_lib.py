@@ -35,6 +35,7 @@ _SIGS = {
     "mofo_last_error": (C.c_char_p, []),
     "mofo_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
+    "mofo_gemm_route_counts": (_i, [C.POINTER(_ll), _i, _i]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mofo_layernorm_fwd_q": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),

@@ -909,6 +909,12 @@ static bool gemm8_has(int op, int epi) {
     return false;
 }
 
+// launches per kernel family since the last reset (mofo_gemm_route_counts): tests assert that a model-level parity run really went
+// through the shape-routed forms it is meant to cover
+enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_N = 8 };
+static long long g_route[ROUTE_N];
+#define ROUTE(k) __atomic_fetch_add(&g_route[k], 1LL, __ATOMIC_RELAXED)
+
 template <int LA, int LB, int EPI>
 int launch(const GroupP& g, int mi, hipStream_t s) {
     if (mi == 16) {
@@ -917,6 +923,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
             const char* e = getenv("MOFO_GEMM8_GRID");   // persistent blocks (tests force a few so that every block walks several tiles)
             const int cap = e && atoi(e) > 0 ? atoi(e) : 256;
             hipLaunchKernelGGL((gemm8_kernel<LA, LB, EPI>), dim3(total < cap ? total : cap), dim3(512), 0, s, g, total);
+            ROUTE(ROUTE_GEMM8);
             MOFO_CHECK_LAUNCH("mofo_gemm(gemm8)");
             return MOFO_OK;
         } else {
@@ -940,23 +947,29 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         }
         if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && ((forced < 0 && ksplit_on) || forced == 3)) {
             hipLaunchKernelGGL((gemm_ksplit_kernel<LA, LB, EPI>), dim3(total), dim3(512), 0, s, p, total);
+            ROUTE(ROUTE_KSPLIT);
         } else if (mi == 8) {
             const dim3 pgrid(total < 512 ? total : 512);
             hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 8>), pgrid, block, 0, s, p, total);
+            ROUTE(ROUTE_PERSIST8);
         } else if (var == 2) {
+            ROUTE(ROUTE_PERSIST);
             const dim3 pgrid(total < 768 ? total : 768);
             if (mi == 2) hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 2>), pgrid, block, 0, s, p, total);
             else hipLaunchKernelGGL((gemm_persistent_kernel<LA, LB, EPI, 4>), pgrid, block, 0, s, p, total);
         } else if (mi == 2) {
+            ROUTE(ROUTE_TILE);
             if (var == 3) var = 1;
             if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 2>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 2>), grid, block, 0, s, g);
         } else {
+            ROUTE(ROUTE_TILE);
             if (var == 3) var = 1;
             if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
             else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
         }
     } else {
+        ROUTE(ROUTE_TILE);
         const int var = forced >= 0 ? (forced != 0) : 1;
         if (var == 0) hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 0, 4>), grid, block, 0, s, g);
         else hipLaunchKernelGGL((gemm_kernel<LA, LB, EPI, 1, 4>), grid, block, 0, s, g);
@@ -1077,6 +1090,7 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
             if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 2>), dim3(total), dim3(256), 0, s, p, total);
             else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 4>), dim3(total), dim3(256), 0, s, p, total);
         }
+        ROUTE(ROUTE_FP8);
         MOFO_CHECK_LAUNCH("mofo_gemm(fp8)");
         return MOFO_OK;
     }
@@ -1167,6 +1181,14 @@ extern "C" int mofo_debug_trace_it_read(void* dst_host, size_t bytes) {
     return hipMemcpyFromSymbol(dst_host, HIP_SYMBOL(g_trace_it), bytes) == hipSuccess ? 0 : MOFO_ERUNTIME;
 }
 #endif
+
+extern "C" int mofo_gemm_route_counts(long long* out, int n, int reset) {
+    if ((!out && n > 0) || n < 0 || n > ROUTE_N) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_route_counts: out[0..n), n <= %d", (int)ROUTE_N);
+    for (int k = 0; k < n; ++k) out[k] = __atomic_load_n(&g_route[k], __ATOMIC_RELAXED);
+    if (reset)
+        for (int k = 0; k < ROUTE_N; ++k) __atomic_store_n(&g_route[k], 0LL, __ATOMIC_RELAXED);
+    return MOFO_OK;
+}
 
 extern "C" int mofo_gemm(const mofo_gemm_args* a, void* stream) {
     if (!a) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: null args");

@@ -84,14 +84,18 @@ __device__ __forceinline__ void g8_stage_half(__amdgpu_buffer_rsrc_t r, int v, i
         asm volatile("" ::: "memory");                                                     \
     } while (0)
 
-// stores per wave in the epilogue of one 128 x 64 wave tile (for the vmcnt budget of the first K-tile after it)
+// A LOWER bound on the stores a wave issues in the epilogue of one FULL 128 x 64 wave tile (the vmcnt budget of the first K-tile
+// after it: `vmcnt(8 + S)` retires the prefetched loads that sit BEHIND the epilogue's S stores in the in-order counter only if
+// the wave really issued >= S stores -- a larger S waits for LESS, so S must never exceed the true count; a smaller S only
+// over-waits).  Ragged tiles take the bounds-checked epilogue path, whose row groups may be branched around: the caller falls
+// back to S = 0 after them.
 template <int EPI>
 constexpr int g8_epi_stores() {
     return EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16 ? 16
          : EPI == MOFO_EPI_BIAS_GELU ? 32
          : EPI == MOFO_EPI_POS_BF16 ? 32
          : EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_POS_F32 ? 32
-         : 55;   // F32: 32 plain stores, or one atomic per row when accumulating (then the wait clamps: over-waiting is safe)
+         : 32;   // F32: 32 plain 4-row stores; the accumulating form issues one atomic per row (128 >= 32)
 }
 
 #ifdef MOFO_GEMM_TRACE
@@ -194,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
 
     float* ep = (float*)(smem + G8_RING) + wave * (16 * 64);
     bool first_tile = true;
+    bool prev_full = false;                    // the previous tile took the branch-free (full-tile) epilogue: its store count is known
     for (;;) {
         const int wnext = w + (int)gridDim.x;
         const bool has_next = wnext < total;
@@ -219,7 +224,7 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
             const bool o1 = kt + 1 >= nk, o2 = kt + 2 >= nk;
             const bool e1 = !o1 || has_next, e2 = !o2 || has_next;
             const bool tail = !e2;                          // last two K-tiles of the stream: nothing younger to leave in flight
-            const bool after_epi = (kt == 0) && !first_tile;
+            const bool after_epi = (kt == 0) && !first_tile && prev_full;   // else: plain W1 / W3 (waits for the epilogue's stores too)
 #ifdef MOFO_GEMM_TRACE
             const bool trace_on = first_tile && kt == 6;
 #endif
@@ -329,9 +334,11 @@ __global__ __launch_bounds__(512, 2) void gemm8_kernel(GroupP G, int total) {
         if (wr == 0) __builtin_amdgcn_s_barrier();          // re-align the two groups for the epilogue
         __builtin_amdgcn_sched_barrier(0);
 
-        epilogue<EPI, 8, 8>(p, acc, ep, tc.m0 + wr * 128, tc.n0 + wc * 64, (tc.m0 + G8_TM <= p.M) && (tc.n0 + G8_TN <= p.N), lane, false);
+        const bool full_tile = (tc.m0 + G8_TM <= p.M) && (tc.n0 + G8_TN <= p.N);
+        epilogue<EPI, 8, 8>(p, acc, ep, tc.m0 + wr * 128, tc.n0 + wc * 64, full_tile, lane, false);
         if (!has_next) break;
         first_tile = false;
+        prev_full = full_tile;
         w = wnext;
         tc = tn;
         cur = nxt;

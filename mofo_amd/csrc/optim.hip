@@ -49,9 +49,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // (engine_for_pretraining.py:168-170); here the update is already enqueued when the host reads the loss, so the kernel
     // itself declines to touch masters, moments and the bf16 shadow when the step is bad.  Block-uniform: every thread reads
     // the same three words.
-    if (gate_finite && !(fabsf(gate_finite[0]) <= 3.402823466e38f)) return;      // NaN or +-inf
-    if (gate_zero && gate_zero[0] != 0) return;                                  // status word set (e.g. ragged mask)
-    if (gate_one && gate_one[0] != 1.0f) return;                                 // fused loss back-propagated with upstream != 1
+    // A skipped update still answers the norm request: every block leaves NaN in its partial, so the norm reduced behind this
+    // launch (norm_final_kernel / mofo_norm_finalize) reads NaN instead of whatever the previous step left there.
+    const bool bad = (gate_finite && !(fabsf(gate_finite[0]) <= 3.402823466e38f))    // NaN or +-inf
+                     || (gate_zero && gate_zero[0] != 0)                             // status word set (e.g. ragged mask)
+                     || (gate_one && gate_one[0] != 1.0f);                           // fused loss back-propagated with upstream != 1
+    if (bad) {
+        if (sumsq_partial && threadIdx.x == 0) sumsq_partial[blockIdx.x] = __builtin_nanf("");
+        return;
+    }
     float ssq = 0.f;                    // sum of squares of the (unscaled) gradients this thread reads, if asked for
     float gm = grad_mult;
     if (max_norm > 0.f && grad_norm) {

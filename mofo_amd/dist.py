@@ -44,6 +44,48 @@ class GradSync:
         g = self.model.runtime().store.grads[lo:hi]
         self.handles.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=self.pg, async_op=True))
 
+    def value_check(self, run_backward, tol: float = 1e-4):
+        """Does the OVERLAPPED exchange deliver the sum over ranks of the COMPLETE local gradients?  ``run_backward()`` runs one
+        forward + zero_grad + backward on fixed inputs (no optimizer step).  Pass 1 runs it with the exchange switched off,
+        synchronises the device and all-reduces a saved copy of the local gradients (nothing can be early there); pass 2 runs
+        the production path, where each range is handed to the all-reduce on the side stream behind an event while backward
+        still runs (runtime._seg_now).  A range exchanged before its last weight-gradient launch had finished shows up as an
+        O(1) relative error; float-atomic reordering in the split weight gradients stays below ``tol``.  The one check a
+        one-rank RCCL group and gloo's synchronous CUDA path cannot make: run it on the first N > 1 job
+        (bench.py does, config.allreduce_value_check).  Returns {"ok", "max_rel", "worst_range", "ranges"}; collective."""
+        st = self.model.runtime().store
+        dev_sync = torch.cuda.synchronize if st.grads.is_cuda else (lambda: None)
+        was = self.enabled
+        self.enabled = False
+        try:
+            run_backward()
+        finally:
+            self.enabled = was
+        launched = list(self.launched)
+        self.handles.clear()
+        self.launched.clear()
+        dev_sync()
+        ref = st.grads.clone()
+        if was:
+            dist.all_reduce(ref, op=dist.ReduceOp.SUM, group=self.pg)
+        dev_sync()
+        run_backward()
+        self.finish()
+        dev_sync()
+        worst, worst_rng = 0.0, None
+        for idx, lo, hi in (launched or [(0, 0, st.grads.numel())]):
+            a, b = st.grads[lo:hi].double(), ref[lo:hi].double()
+            rel = float((a - b).norm() / b.norm().clamp_min(1e-30))
+            if not rel <= worst:          # NaN-aware
+                worst, worst_rng = rel, (idx, lo, hi)
+        ok = bool(worst <= tol)
+        if was:
+            flag = torch.tensor([1.0 if ok else 0.0, worst if worst == worst else float("inf")], dtype=torch.float64, device=st.grads.device)
+            dist.all_reduce(flag[:1], op=dist.ReduceOp.MIN, group=self.pg)
+            dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX, group=self.pg)
+            ok, worst = bool(flag[0].item() == 1.0), float(flag[1].item())
+        return {"ok": ok, "max_rel": worst, "worst_range": worst_rng, "ranges": len(launched)}
+
     def finish(self):
         """join the outstanding all-reduces (the current stream waits; the host does not block on nccl)"""
         for h in self.handles:

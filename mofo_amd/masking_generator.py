@@ -79,13 +79,36 @@ class DeviceTubeMaskingGenerator(_TubeGeometry):
         mask = gen(batch_size, out=model.input_buffers(batch_size, n_vis)[1])     # uint8 [B, 1568] on the device, 1 = masked
     """
 
-    def __init__(self, input_size, mask_ratio, seed=0, rank=0, world_size=1):
+    def __init__(self, input_size, mask_ratio, seed=0, rank=None, world_size=None):
         """``rank`` / ``world_size`` (data parallelism): the clip counter of a draw is ``step * global_batch + rank * batch_size + i``,
         so ranks that share one ``seed`` still draw DIFFERENT masks (the reference's workers are seeded ``seed + rank``,
-        run_mae_pretraining.py:166) and a job's masks do not depend on how its global batch is split over ranks."""
+        run_mae_pretraining.py:166) and a job's masks do not depend on how its global batch is split over ranks.  Left at None
+        they come from the initialised torch.distributed group, else from RANK / WORLD_SIZE (utils.py:277-296), else 0 / 1."""
         super().__init__(input_size, mask_ratio)
         self.seed, self.clips_drawn = int(seed), 0
+        if rank is None or world_size is None:
+            r, w = self._ambient_rank()
+            rank = r if rank is None else rank
+            world_size = w if world_size is None else world_size
         self.rank, self.world_size = int(rank), max(1, int(world_size))
+
+    @staticmethod
+    def _ambient_rank():
+        import os
+        try:
+            import torch.distributed as dist
+            if dist.is_available() and dist.is_initialized():
+                return dist.get_rank(), dist.get_world_size()
+        except Exception:
+            pass
+        return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+    def state_dict(self):
+        """what a checkpoint needs so that a resumed run continues the mask stream instead of replaying step 0"""
+        return {"seed": self.seed, "clips_drawn": self.clips_drawn}
+
+    def load_state_dict(self, state):
+        self.seed, self.clips_drawn = int(state["seed"]), int(state["clips_drawn"])
 
     def __call__(self, batch_size, out=None, device=None):
         import torch

@@ -199,6 +199,16 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
     return a, 2.0 * M * N * K, nbytes
 
 
+GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8")
+
+
+def gemm_route_counts(reset=False):
+    """launches per GEMM main-loop family since the last reset (include/mofo_hip.h: mofo_gemm_route_counts)"""
+    buf = (C.c_longlong * 8)()
+    _lib.check(_lib.load().mofo_gemm_route_counts(buf, 8, 1 if reset else 0), "mofo_gemm_route_counts")
+    return {name: int(buf[i]) for i, name in enumerate(GEMM_ROUTES)}
+
+
 def colsum_bf16(X, out):
     _chk(X, BF16, "X", 2), _chk(out, F32, "out", 1)
     if out.numel() != X.shape[1]:

@@ -92,12 +92,21 @@ class FusedAdamW(torch.optim.Optimizer):
             st.attach_grads()
 
     @torch.no_grad()
+    def undo_skipped_step(self):
+        """the last step() was declined on the device (non-finite loss / status word): take its count back"""
+        if self._step > 0:
+            self._step -= 1
+
     def step(self, closure=None, grad_norm=None, max_norm=0.0, norm_out=None, ranges=None):
         """``norm_out`` (device f32 [1], only without clipping): the update pass also leaves the global gradient L2 norm
         there -- the norm is reported, not needed before the update, so the gradients are read once instead of twice.
         ``ranges`` (data parallelism, un-clipped step): iterable of ``(lo, hi, wait)`` tiling the flat buffers in the order
         their gradient all-reduces were issued; ``wait()`` makes the stream wait for that range's exchange, then the range
-        is updated -- the HBM-bound update of the early ranges runs while the last range is still on the wire."""
+        is updated -- the HBM-bound update of the early ranges runs while the last range is still on the wire.
+        Gate: the device-side gate (mofo_adamw_gated) can decline the update AFTER this call has advanced the host-side step
+        counter; a caller that keeps training past a skipped step (the drop-in engine does not: it exits on the non-finite
+        loss like engine_for_pretraining.py:168-170) calls ``undo_skipped_step()`` so the bias correction stays in step.  The
+        gate reflects the last backward only: under gradient accumulation, check every micro-batch's loss on the host."""
         if closure is not None:
             raise NotImplementedError("closure")
         rt, st = self._bind()

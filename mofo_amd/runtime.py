@@ -350,7 +350,7 @@ class PretrainRuntime:
         self.norm_partial = torch.empty(1024, dtype=F32, device=self.dev)
         dmax = max(dims.enc_dim if enc_prefix is not None else 0, dims.dec_dim if dec_prefix is not None else 0, 64)
         self.ln_ws = torch.empty(2 * 1024 * dmax, dtype=F32, device=self.dev)   # LN-backward dgamma/dbeta block partials
-        self._ln_dmax, self._ln_pool, self._ln_pending = dmax, [], []
+        self._ln_dmax, self._ln_pool, self._ln_pending, self._ln_retired = dmax, [], [], []
         self.norm_out = torch.zeros(1, dtype=F32, device=self.dev)
 
     # ------------------------------------------------------------------ LayerNorm backward with grouped dgamma / dbeta reduction
@@ -366,6 +366,9 @@ class PretrainRuntime:
         if k >= len(self._ln_pool):
             self._ln_pool.append(torch.empty(need, dtype=F32, device=self.dev))
         elif self._ln_pool[k].numel() < need:
+            # a recorded launch list of ANOTHER workspace may hold this buffer's raw pointer (ops.replay passes data_ptr ints,
+            # incl. the mofo_layernorm_bwd_finalize pointer table): the smaller buffer is retired, never freed
+            self._ln_retired.append(self._ln_pool[k])
             self._ln_pool[k] = torch.empty(need, dtype=F32, device=self.dev)
         ws = self._ln_pool[k]
         nb = ops.layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, None, None, partial_ws=ws, **kw)

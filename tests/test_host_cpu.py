@@ -251,6 +251,74 @@ def test_data_parallel_gradient_mean_two_ranks(tmp_path):
     assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
+def _dp_check_worker(rank, world, port, out):
+    """GradSync.value_check on two gloo ranks: the production order passes; a backward that finishes a range AFTER handing it to
+    the all-reduce (what a too-early side-stream hand-off would amount to) is caught"""
+    import torch.distributed as dist
+    from mofo_amd.dist import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    model = _tiny_model()
+    rt, st = _cpu_runtime(model)
+    model.runtime = lambda: rt
+    sync = GradSync(model).install()
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(st.total, generator=g)
+    lo1, hi1 = rt.segments[1]
+
+    def good():
+        st.grads.copy_(local / world)
+        for idx in range(len(rt.segments)):
+            rt._seg_now(idx)
+
+    def early():                       # range 1 is handed over while its "last weight gradient" is still missing
+        st.grads.copy_(local / world)
+        st.grads[lo1:hi1].zero_()
+        for idx in range(len(rt.segments)):
+            rt._seg_now(idx)
+        for h in sync.handles:
+            h.wait()
+        st.grads[lo1:hi1] += local[lo1:hi1] / world
+
+    ok = sync.value_check(good)
+    bad = sync.value_check(early)
+    torch.save({"ok": ok, "bad": bad, "seg1": (lo1, hi1)}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_allreduce_value_check_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    out = str(tmp_path / "chk")
+    mp.spawn(_dp_check_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    for i in range(world):
+        r = torch.load(out + f".{i}")
+        assert r["ok"]["ok"] and r["ok"]["max_rel"] < 1e-6 and r["ok"]["ranges"] == 4
+        assert not r["bad"]["ok"] and r["bad"]["max_rel"] > 0.1
+        assert tuple(r["bad"]["worst_range"][1:]) == tuple(r["seg1"])          # ... and names the range that was early
+
+
+def test_device_mask_generator_rank_defaults_and_state(monkeypatch):
+    """rank / world of the device-side mask generator default to the launcher's environment (utils.py:277-296 reads the same
+    variables), and its position in the mask stream is checkpointable"""
+    from mofo_amd.masking_generator import DeviceTubeMaskingGenerator
+    monkeypatch.setenv("RANK", "3")
+    monkeypatch.setenv("WORLD_SIZE", "8")
+    g = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=5)
+    assert (g.rank, g.world_size) == (3, 8)
+    g2 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=5, rank=0, world_size=1)
+    assert (g2.rank, g2.world_size) == (0, 1)
+    monkeypatch.delenv("RANK")
+    monkeypatch.delenv("WORLD_SIZE")
+    g3 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=5)
+    assert (g3.rank, g3.world_size) == (0, 1)
+    g3.clips_drawn = 96
+    g4 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=0)
+    g4.load_state_dict(g3.state_dict())
+    assert (g4.seed, g4.clips_drawn) == (5, 96)
+
+
 # ------------------------------------------------------------------------------------------------ "next" rows (SURVEY.md 8f-4)
 def test_finetune_model_schema_and_checkpoint_mapping():
     """state_dict schema of the fine-tune model = the reference's (oracle.finetune_param_shapes, pinned by finetune_*.npz), a
