@@ -68,7 +68,7 @@ int mofo_gemm(const mofo_gemm_args* args, void* stream);
 int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
 /* Diagnostics (host side, no device work): launches per main-loop family since the last reset -- out[0] one tile per block,
  * [1] persistent 64/128-row tiles, [2] persistent 256-row tiles, [3] in-block split-K, [4] the 256 x 256 counted-vmcnt kernel,
- * [5] e4m3, [6..7] reserved.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
+ * [5] e4m3, [6] one 128 x 128 tile per CU with the reduction halved over two wave groups, [7] reserved.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
 int mofo_gemm_route_counts(long long* out, int n, int reset);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */

@@ -876,6 +876,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
 }
 
 #include "gemm8.h"
+#include "gemm_k2.h"
 
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
 // (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
@@ -911,7 +912,7 @@ static bool gemm8_has(int op, int epi) {
 
 // launches per kernel family since the last reset (mofo_gemm_route_counts): tests assert that a model-level parity run really went
 // through the shape-routed forms it is meant to cover
-enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_N = 8 };
+enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_K2 = 6, ROUTE_N = 8 };
 static long long g_route[ROUTE_N];
 #define ROUTE(k) __atomic_fetch_add(&g_route[k], 1LL, __ATOMIC_RELAXED)
 
@@ -928,6 +929,22 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
             return MOFO_OK;
         } else {
             MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: the 256-tile kernel is not built for this (op, epilogue)");
+        }
+    }
+    if (mi == 32) {   // one 128 x 128 tile per CU, two K-halves with two-stage rings (gemm_k2.h)
+        if constexpr (LA == OPL_ROW) {
+            const int total = g.start[1];
+            const char* e = getenv("MOFO_GEMM_K2_STAG");         // read per call (A/B in one process)
+            const char* er = getenv("MOFO_GEMM_K2_ROT");
+            GemmP pk = g.p[0];
+            if (er) pk.rotate_tile = atoi(er);
+            if (!e || atoi(e) != 0) hipLaunchKernelGGL((gemm_k2_kernel<LA, LB, EPI, true>), dim3(total), dim3(512), 0, s, pk, total);
+            else hipLaunchKernelGGL((gemm_k2_kernel<LA, LB, EPI, false>), dim3(total), dim3(512), 0, s, pk, total);
+            ROUTE(ROUTE_K2);
+            MOFO_CHECK_LAUNCH("mofo_gemm(k2)");
+            return MOFO_OK;
+        } else {
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: the one-tile-per-CU split-K kernel is built for NT / NN");
         }
     }
     const int forced = forced_variant();
@@ -1156,10 +1173,25 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
         }
         if (legal && (mode == 1 || gemm8_wanted(a, count))) mi = 16;
     }
+    // One 128 x 128 tile per CU with the reduction halved over two wave groups (gemm_k2.h): NT / NN problems whose 128 x 128 tiling
+    // gives at most one tile per CU and whose reduction is worth a two-stage ring -- the encoder's N = 768 GEMMs at 5 120 rows.
+    // MOFO_GEMM_K2 = 0: never, 1: wherever legal, unset: by shape.
+    if (mi != 16) {
+        const char* e = getenv("MOFO_GEMM_K2");     // read per call: A/B switches inside one process
+        const int mode = e ? atoi(e) : -1;
+        const bool legal = mode != 0 && count == 1 && (a[0].op == MOFO_GEMM_NT || a[0].op == MOFO_GEMM_NN) && a[0].splits <= 1 && !a[0].accumulate &&
+                           a[0].K % 64 == 0;
+        if (legal) {
+            // same-process A/B at the ViT-B step's shapes (tools/gemm_k2_ab.py, profiles/r04_gemm_k2_ab.txt): 5120 x 768 x 3072 NT
+            // 34.9 -> 32.5 us, NN 32.4 -> 29.2, K = 2304 NN 25.7 -> 23.5; at K = 768 (six k-stages per group) the old forms are at par
+            const long long t128 = (long long)ceil_div(a[0].M, 128) * ceil_div(a[0].N, BN);
+            if (mode == 1 ? t128 <= 4096 : (t128 <= 256 && a[0].K >= 1536)) mi = 32;
+        }
+    }
     for (int i = 0; i < count; ++i) {
         if (a[i].op != a[0].op || a[i].epilogue != a[0].epilogue) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: problems must share op and epilogue");
         int blocks = 0;
-        const int rc = fill_problem(&a[i], g.p[i], mi == 16 ? 256 : 32 * mi, mi == 16 ? 256 : BN, blocks);
+        const int rc = fill_problem(&a[i], g.p[i], mi == 16 ? 256 : (mi == 32 ? 128 : 32 * mi), mi == 16 ? 256 : BN, blocks);
         if (rc) return rc;
         g.start[i + 1] = g.start[i] + blocks;
     }

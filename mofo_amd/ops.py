@@ -199,7 +199,7 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
     return a, 2.0 * M * N * K, nbytes
 
 
-GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8")
+GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8", "k2")
 
 
 def gemm_route_counts(reset=False):

@@ -623,7 +623,12 @@ class PretrainRuntime:
         if not S.pending:
             return
         group, S.pending = S.pending, []
-        mode = os.environ.get("MOFO_WGRAD_STREAM", "side")
+        # Default since round 4: the SAME stream as the activation-gradient chain.  With round 4's kernels two same-box pairs measured
+        # 11.67 / 11.67 ms (main) against 11.76 / 11.71 (side) for the step and 4.54 against 4.69 ms for the encoder-only step
+        # (profiles/r04_wgrad_stream_k2.txt): a CU-filling grouped launch beside the chain slows the chain's kernels by what it hides,
+        # and the one-tile-per-CU GEMMs (gemm_k2.h: 128 KiB of LDS) cannot start on a CU that still holds weight-gradient blocks.
+        # MOFO_WGRAD_STREAM=side restores the side stream (main_enc / main_dec: per pass).
+        mode = os.environ.get("MOFO_WGRAD_STREAM", "main")
         if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
             self._wgrad_group(group)          # same stream: no fork / join events (each costs ~10 us of queue bubble)
             return

@@ -163,8 +163,11 @@ def test_fp8_quantisation_kernels(dev):
     assert scales[1].tolist() == [8.0, 0.125] and float(amx.abs().max()) == 0.0
 
 
-def test_gemm_nt_pos_rowmap(dev):
+@pytest.mark.parametrize("k2", ["0", "1"])
+def test_gemm_nt_pos_rowmap(dev, monkeypatch, k2):
+    """k2 = 1: the same through the one-tile-per-CU split-K kernel (the patch embed at 5 120 rows is routed to it)"""
     from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM_K2", k2)
     Bc, nv, Ntok, K, N = 3, 20, 50, 128, 192
     M = Bc * nv
     A = _rand((M, K), dev, 1)
@@ -336,6 +339,63 @@ def test_gemm8_counted_vmcnt_family(dev, monkeypatch, M, N, K):
     ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, [(dy, x, g, dict(splits=1, accumulate=False)) for dy, x, g in zip(dYs, Xs, Gs)])
     for dy, x, g in zip(dYs, Xs, Gs):
         close(g, dy.float().t() @ x.float())
+
+
+@pytest.mark.parametrize("stag", ["1", "0"])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 768), (640, 768, 3072), (1000, 520, 704), (300, 136, 192), (5120, 768, 2304)])
+def test_gemm_k2_one_tile_per_cu_family(dev, monkeypatch, M, N, K, stag):
+    """The one-128x128-tile-per-CU kernel (csrc/gemm_k2.h: two wave groups, each half of the reduction through a two-stage LDS ring
+    with a counted vmcnt), forced with MOFO_GEMM_K2=1, with and without the half-step stagger: every NT / NN epilogue, whole and
+    ragged tiles, odd numbers of k-stages (K = 704 -> 11: the second group's last stage is empty; K = 64 / 192: one group has one
+    stage or none in flight), against fp32 torch on the same bf16 operands -- element-wise, so that a stage read before its LDS-DMA
+    landed (a race a norm would average away) shows."""
+    from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM_K2", "1")
+    monkeypatch.setenv("MOFO_GEMM_K2_STAG", stag)
+
+    def close(C, want, tol=2.5e-2):
+        want = want.float()
+        bad = ((C.float() - want).abs() > tol * want.abs().max()).sum().item()
+        assert bad == 0, f"{bad} elements off"
+        assert _rel(C, want) < 6e-3
+
+    A = _rand((M, K), dev, 1)
+    B = _rand((N, K), dev, 2, 0.05)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    ref = A.float() @ B.float().t()
+    ops.gemm_route_counts(reset=True)
+    Cb = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, B, Cb, bias=bias)
+    close(Cb, ref + bias)
+    C2 = torch.empty_like(Cb)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, A, B, Cb, C2=C2, bias=bias)
+    close(Cb, ref + bias)
+    close(C2, torch.nn.functional.gelu(ref + bias))
+    R = _rand((M, N), dev, 4, 1.0, F32)
+    Cf = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, B, Cf, bias=bias, resid=R)
+    close(Cf, ref + bias + R)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, A, B, Cb, bias=bias, aux=R.to(BF16))
+    close(Cb, ref + bias + R.to(BF16).float())
+    ops.gemm(ops.GEMM_NT, ops.EPI_F32, A, B, Cf)
+    close(Cf, ref)
+    Bn = B.t().contiguous()                      # [K, N]: dgrad (NN), B read reduction-strided
+    ops.gemm(ops.GEMM_NN, ops.EPI_BF16, A, Bn, Cb)
+    close(Cb, ref)
+    H = _rand((M, N), dev, 5, 1.0)
+    h = H.float().requires_grad_(True)
+    g, = torch.autograd.grad(torch.nn.functional.gelu(h).sum(), h)
+    ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, A, Bn, Cb, aux=H)
+    close(Cb, ref * g)
+    ops.gemm(ops.GEMM_NN, ops.EPI_F32, A, Bn, Cf)
+    close(Cf, ref)
+    assert ops.gemm_route_counts()["k2"] == 8
+    # repeated launches of the same problem are bit-identical (a stage consumed before it landed would differ run to run)
+    first = torch.empty_like(Cb)
+    ops.gemm(ops.GEMM_NN, ops.EPI_BF16, A, Bn, first)
+    for _ in range(20):
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, A, Bn, Cb)
+        assert torch.equal(Cb, first)
 
 
 def test_gemm_rejects_bad_shapes(dev):
