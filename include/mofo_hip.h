@@ -123,6 +123,19 @@ int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dout, int lddo
                           int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
 int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                            int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
+/* Query RANGES: only the query rows q_begin .. N - 1 of every clip are worked on -- the last decoder block, whose visible-token
+ * outputs nothing reads (modeling_pretrain.py:157 keeps x[:, -return_token_num:]; the visible tokens are rows 0 .. n_vis - 1 of a
+ * clip, modeling_pretrain.py:259).  `out` / `dout` hold those N - q_begin rows per clip COMPACTLY: bf16 [B * (N - q_begin), H*64];
+ * qkv, dqkv, lse2 and delta keep whole-sequence indices (keys and values are still all N rows; dq rows below q_begin are NOT
+ * written: clear them).  q_begin = 0 is exactly the entries above. */
+int mofo_attention_fwd_range(const void* qkv, int ldqkv, int B, int N, int H, float scale, int q_begin,
+                             void* out, int ldo, float* lse2, void* stream);
+int mofo_attention_delta_range(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, int q_begin, float* delta,
+                               void* stream);
+int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                                int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
+int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                                 int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
 /* The ONE-pass form mofo_attention_bwd uses for N > 160 (5 MFMA products per (query tile, key tile) pair instead of the 7
  * of the dq + dkv passes): blocks own strips of key tiles, keep dK / dV in registers and ADD their strip's dQ tiles to the
  * q third of dqkv with packed-bf16 atomics -- that third must be ZERO on entry; mofo_attention_delta_zero_dq computes delta

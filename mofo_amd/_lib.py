@@ -51,6 +51,10 @@ _SIGS = {
     "mofo_attention_delta": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "mofo_attention_bwd_dq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_attention_bwd_dkv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
+    "mofo_attention_fwd_range": (_i, [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
+    "mofo_attention_delta_range": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "mofo_attention_bwd_dq_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
+    "mofo_attention_bwd_dkv_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "mofo_attention_delta_zero_dq": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "mofo_attention_bwd_onepass": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),

@@ -160,14 +160,18 @@ template <int NW, int MODE, bool WHOLE, bool U2 = false>
 __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
-                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta, float thr) {
+                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta, float thr, int qb) {
+    // qb: first query row of every clip that is worked on (0 = all); `out` / `dout` then hold the N - qb rows of a clip COMPACTLY
+    // ([B * (N - qb), H * 64]) while qkv, dqkv, lse2 and delta keep whole-sequence row indices.  The last decoder block's
+    // visible-token queries feed nothing (modeling_pretrain.py:157 keeps x[:, -return_token_num:]): the runtime skips them.
     constexpr int NBUF = WHOLE ? 5 : 2;
     __shared__ __attribute__((aligned(16))) unsigned char smem[NBUF * 2 * TILE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
     int xb, b, h;
     if (!decode_block(nx, G, H, xb, b, h)) return;
     const int D = H * HD;
-    const int q0 = (xb * NW + wave) * 32;
+    const int q0 = qb + (xb * NW + wave) * 32;
+    const int nq = N - qb;
     const bf16_t* base = qkv + (size_t)b * N * ldqkv;
     const bf16_t* qp = base + h * HD;
     const bf16_t* kp = base + D + h * HD;
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     bf16x8 dof[4];
     float L2 = 0.f, dl = 0.f;
     if constexpr (MODE == 1) {
-        const bf16_t* dop = dout + ((size_t)b * N + qrow) * lddo + h * HD;
+        const bf16_t* dop = dout + ((size_t)b * nq + (qrow - qb)) * lddo + h * HD;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(dop + 16 * ks + 8 * hh);
         L2 = lse2[((size_t)b * H + h) * N + qrow];
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     if constexpr (MODE == 0) {
         const float lt = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / lt;
-        store_T(out + ((size_t)b * N + qi) * ldo + h * HD, o0, o1, inv, hh);
+        store_T(out + ((size_t)b * nq + (qi - qb)) * ldo + h * HD, o0, o1, inv, hh);
         if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m * c + fast_log2(lt);
     } else {
         store_T(dqkv + ((size_t)b * N + qi) * lddqkv + h * HD, o0, o1, scale, hh);
@@ -374,7 +378,8 @@ template <int NW, bool WHOLE, bool U2 = false, int FOLD = 0>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
                                                             const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                            bf16_t* __restrict__ dqkv, int lddqkv, int stagger) {
+                                                            bf16_t* __restrict__ dqkv, int lddqkv, int stagger, int qb) {
+    // qb: the query rows qb .. N - 1 of every clip contribute (0 = all); `dout` holds them compactly (see attn_q_kernel)
     constexpr bool PRELOAD = U2;
     constexpr bool PRELOAD_C = U2;
     constexpr bool PAIR = U2 && !WHOLE;    // two query tiles staged per barrier (four LDS tile buffers): -2 %
@@ -394,7 +399,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     const bf16_t* qp = base + h * HD;
     const bf16_t* kp = base + D + h * HD;
     const bf16_t* vp = base + 2 * D + h * HD;
-    const bf16_t* dop = dout + (size_t)b * N * lddo + h * HD;
+    const bf16_t* dop = dout + ((long long)b * (N - qb) - qb) * lddo + h * HD;   // row r of the clip sits at compact row r - qb
     const float* lp = lse2 + ((size_t)b * H + h) * N;
     const float* dp_ = delta + ((size_t)b * H + h) * N;
     const int ki = k0 + (lane & 31);
@@ -420,17 +425,17 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     }
     f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16();
 
-    const int nqt = (N + 31) >> 5;
+    const int nqt = (N - qb + 31) >> 5;
     u32x4 qreg = {0, 0, 0, 0}, oreg = {0, 0, 0, 0}, qreg2 = {0, 0, 0, 0}, oreg2 = {0, 0, 0, 0};
     float sreg = 0.f, sreg2 = 0.f;
     auto gload_to = [&](int qt, u32x4& qr, u32x4& orr, float& sr) {
         if (tid < 256) {
-            int r = qt * 32 + (tid >> 3);
+            int r = qb + qt * 32 + (tid >> 3);
             r = r < N ? r : N - 1;
             qr = *(const u32x4*)(qp + (size_t)r * ldqkv + (tid & 7) * 8);
             orr = *(const u32x4*)(dop + (size_t)r * lddo + (tid & 7) * 8);
             if (tid < 64) {
-                const int qq = qt * 32 + (tid & 31);
+                const int qq = qb + qt * 32 + (tid & 31);
                 // a query row beyond N must contribute nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
                 if (tid < 32) sr = qq < N ? lp[qq] : 1.0e30f;
                 else sr = qq < N ? dp_[qq] : 0.f;
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             const int ch = (lane & 7) ^ swz(rl);
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                int r = (2 * pr + u) * 32 + rl;
+                int r = qb + (2 * pr + u) * 32 + rl;
                 r = r < N ? r : N - 1;
                 dma_b128(qp + (size_t)r * ldqkv + ch * 8, lds0 + u * BUF + wave_u * 1024);
                 dma_b128(dop + (size_t)r * lddo + ch * 8, lds0 + u * BUF + TILE + wave_u * 1024);
@@ -474,7 +479,7 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
             if (wave_u == 0) {
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int qq = (2 * pr + u) * 32 + (lane & 31);
+                    const int qq = qb + (2 * pr + u) * 32 + (lane & 31);
                     const float* src = lane < 32 ? (qq < N ? lp + qq : g_pad_row) : (qq < N ? dp_ + qq : g_pad_row + 1);
                     dma_b32(src, lds0 + u * BUF + 2 * TILE);
                 }
@@ -1144,7 +1149,8 @@ __global__ __launch_bounds__(OP_T * 64) void attn_bwd_onepass_kernel(const bf16_
 // `zero_q` (the q third of dqkv, row stride ldz) is cleared on the way for the one-pass backward, whose strips ADD their dQ tiles.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ dout,
                                                          int lddo, int N, int H, long long pairs, float* __restrict__ delta,
-                                                         bf16_t* __restrict__ zero_q, int ldz) {
+                                                         bf16_t* __restrict__ zero_q, int ldz, int qb) {
+    // qb: `out` / `dout` hold the query rows qb .. N - 1 of every clip compactly (tok counts those rows); delta keeps whole-sequence indices
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long pr = i >> 3;
     const int ch = (int)(i & 7);
@@ -1156,7 +1162,10 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         const bf16x8 o = *(const bf16x8*)(out + tok * ldo + h * HD + ch * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part += (float)a[j] * (float)o[j];
-        if (zero_q) *(u32x4*)(zero_q + tok * ldz + h * HD + ch * 8) = u32x4{0u, 0u, 0u, 0u};
+        if (zero_q) {
+            const long long bz = tok / (N - qb);
+            *(u32x4*)(zero_q + (bz * N + qb + (tok - bz * (N - qb))) * ldz + h * HD + ch * 8) = u32x4{0u, 0u, 0u, 0u};
+        }
     }
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
@@ -1164,7 +1173,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     if (pr < pairs && ch == 0) {
         const long long tok = pr / H;
         const int h = (int)(pr - tok * H);
-        const long long b = tok / N, q = tok - b * N;
+        const int nq = N - qb;
+        const long long b = tok / nq, q = qb + (tok - b * nq);
         delta[((size_t)b * H + h) * N + q] = part;
     }
 }
@@ -1197,9 +1207,9 @@ int pick_nw(int N) {
 
 #define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false); } else { LAUNCH_Q_(NW, MODE, false, true); } } while (0)
 #define LAUNCH_Q_(NW, MODE, WH, U2)                                                                                     \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s, \
-                       (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
-                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr())
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N - q_begin, 32 * NW)), dim3(NW * 64), 0, s, \
+                       (const bf16_t*)qkv, ldqkv, ceil_div(N - q_begin, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
+                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr(), q_begin)
 
 static int check_common(const char* who, const void* qkv, int ldqkv, int B, int N, int H) {
     if (!qkv) MOFO_FAIL(MOFO_EINVAL, "%s: null qkv", who);
@@ -1209,10 +1219,21 @@ static int check_common(const char* who, const void* qkv, int ldqkv, int B, int 
     return MOFO_OK;
 }
 
+static int check_range(const char* who, int N, int q_begin) {
+    if (q_begin < 0 || q_begin >= N) MOFO_FAIL(MOFO_EINVAL, "%s: q_begin=%d must be in [0, N=%d)", who, q_begin, N);
+    return MOFO_OK;
+}
+
 extern "C" int mofo_attention_fwd(const void* qkv, int ldqkv, int B, int N, int H, float scale, void* out, int ldo,
                                   float* lse2, void* stream) {
+    return mofo_attention_fwd_range(qkv, ldqkv, B, N, H, scale, 0, out, ldo, lse2, stream);
+}
+
+extern "C" int mofo_attention_fwd_range(const void* qkv, int ldqkv, int B, int N, int H, float scale, int q_begin, void* out, int ldo,
+                                        float* lse2, void* stream) {
     int rc = check_common("mofo_attention_fwd", qkv, ldqkv, B, N, H);
     if (rc) return rc;
+    if ((rc = check_range("mofo_attention_fwd", N, q_begin))) return rc;
     if (!out || !lse2) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_fwd: null output");
     if (ldo < H * 64 || ldo % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd: bad ldo=%d", ldo);
     hipStream_t s = (hipStream_t)stream;
@@ -1236,18 +1257,26 @@ static int bwd_check(const char* who, const void* qkv, int ldqkv, const void* do
     return MOFO_OK;
 }
 
-static int launch_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* zero_q, int ldz, void* stream) {
+static int launch_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* zero_q, int ldz, void* stream,
+                        int q_begin = 0) {
     if (!out || !dout || !delta) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: null pointer");
     if (B <= 0 || N <= 0 || H <= 0 || ldo % 8 || lddo % 8 || (zero_q && ldz % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: bad sizes");
-    const long long pairs = (long long)B * N * H;
+    int rc = check_range("mofo_attention_delta", N, q_begin);
+    if (rc) return rc;
+    const long long pairs = (long long)B * (N - q_begin) * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out, ldo,
-                       (const bf16_t*)dout, lddo, N, H, pairs, delta, (bf16_t*)zero_q, ldz);
+                       (const bf16_t*)dout, lddo, N, H, pairs, delta, (bf16_t*)zero_q, ldz, q_begin);
     MOFO_CHECK_LAUNCH("mofo_attention_delta");
     return MOFO_OK;
 }
 
 extern "C" int mofo_attention_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* stream) {
     return launch_delta(out, ldo, dout, lddo, B, N, H, delta, nullptr, 0, stream);
+}
+
+extern "C" int mofo_attention_delta_range(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, int q_begin, float* delta,
+                                          void* stream) {
+    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, nullptr, 0, stream, q_begin);
 }
 
 // delta AND the cleared q third of dqkv: what mofo_attention_bwd_onepass expects to find
@@ -1281,8 +1310,14 @@ extern "C" int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void
 
 extern "C" int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2_in, const float* delta_in,
                                      int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream) {
+    return mofo_attention_bwd_dq_range(qkv, ldqkv, dout, lddo, lse2_in, delta_in, B, N, H, scale, 0, dqkv, lddqkv, stream);
+}
+
+extern "C" int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2_in, const float* delta_in,
+                                           int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream) {
     int rc = bwd_check("mofo_attention_bwd_dq", qkv, ldqkv, dout, lddo, lse2_in, delta_in, B, N, H, dqkv, lddqkv);
     if (rc) return rc;
+    if ((rc = check_range("mofo_attention_bwd_dq", N, q_begin))) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
     float* lse2 = const_cast<float*>(lse2_in);
@@ -1299,8 +1334,14 @@ extern "C" int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dou
 
 extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                       int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream) {
+    return mofo_attention_bwd_dkv_range(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, 0, dqkv, lddqkv, stream);
+}
+
+extern "C" int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
+                                            int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream) {
     int rc = bwd_check("mofo_attention_bwd_dkv", qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, dqkv, lddqkv);
     if (rc) return rc;
+    if ((rc = check_range("mofo_attention_bwd_dkv", N, q_begin))) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
     {
@@ -1308,7 +1349,7 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
         // MOFO_ATTN_DKV_PP = 0: off, 1: on, 2: on with the exp2 argument folded into the K fragments / S accumulator (read per call).
         const char* e = getenv("MOFO_ATTN_DKV_PP");
         const int mode = e ? atoi(e) : 0;
-        if (mode > 0 && N > 160) {
+        if (mode > 0 && N > 160 && q_begin == 0) {
             const int T = ceil_div(N, 32);
             int nw = 8, best = 1 << 30;
             for (int w = 8; w >= 5; --w) {
@@ -1337,7 +1378,7 @@ extern "C" int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* do
 #define LAUNCH_KV_(NW, WH, U2, FO)                                                                                     \
     hipLaunchKernelGGL((attn_dkv_kernel<NW, WH, U2, FO>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N, 32 * NW)), dim3(NW * 64), 0, s,   \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N, 32 * NW), B * H, N, H, c, scale, (const bf16_t*)dout, lddo,      \
-                       (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv, attn_stagger())
+                       (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv, attn_stagger(), q_begin)
     switch (pick_nw(N)) {
         case 7: LAUNCH_KV(7); break;
         case 5: LAUNCH_KV(5); break;

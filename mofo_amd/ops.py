@@ -360,11 +360,15 @@ def layernorm_bwd_finalize(items):
     _run("mofo_layernorm_bwd_finalize", ("ln_bwd_fin",), sum(8.0 * t[1] * t[2] for t in items), *args, n)
 
 
-def attention_fwd(qkv, B, N, H, scale, out, lse2):
+def attention_fwd(qkv, B, N, H, scale, out, lse2, q_begin=0):
+    """``q_begin`` > 0: only the query rows q_begin .. N - 1 of every clip; ``out`` is then the compact [B * (N - q_begin), H * 64]"""
     _chk(qkv, BF16, "qkv", 2), _chk(out, BF16, "out", 2), _chk(lse2, F32, "lse2")
-    if qkv.shape != (B * N, 3 * H * 64) or out.shape != (B * N, H * 64) or lse2.numel() != B * H * N:
+    if not 0 <= q_begin < N:
+        raise ValueError("attention_fwd: q_begin out of range")
+    if qkv.shape != (B * N, 3 * H * 64) or out.shape != (B * (N - q_begin), H * 64) or lse2.numel() != B * H * N:
         raise ValueError("attention_fwd: shape mismatch")
-    _run("mofo_attention_fwd", ("attn_fwd",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, _p(out), _ld(out), _p(lse2))
+    _run("mofo_attention_fwd_range", ("attn_fwd",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, q_begin, _p(out), _ld(out),
+         _p(lse2))
     return out
 
 
@@ -389,34 +393,38 @@ def ingest_u8(frames, clips):
     return clips
 
 
-def _attn_bwd_chk(qkv, out, dout, lse2, B, N, H, dqkv, delta):
+def _attn_bwd_chk(qkv, out, dout, lse2, B, N, H, dqkv, delta, q_begin=0):
     _chk(qkv, BF16, "qkv", 2), _chk(dout, BF16, "dout", 2), _chk(dqkv, BF16, "dqkv", 2), _chk(lse2, F32, "lse2"), _chk(delta, F32, "delta")
+    if not 0 <= q_begin < N:
+        raise ValueError("attention backward: q_begin out of range")
     if out is not None:
         _chk(out, BF16, "out", 2)
-        if out.shape != (B * N, H * 64):
+        if out.shape != (B * (N - q_begin), H * 64):
             raise ValueError("out shape")
-    if (qkv.shape != (B * N, 3 * H * 64) or dqkv.shape != qkv.shape or dout.shape != (B * N, H * 64)
+    if (qkv.shape != (B * N, 3 * H * 64) or dqkv.shape != qkv.shape or dout.shape != (B * (N - q_begin), H * 64)
             or lse2.numel() != B * H * N or delta.numel() != B * H * N):
         raise ValueError("attention backward: shape mismatch")
 
 
-def attention_delta(out, dout, B, N, H, delta):
+def attention_delta(out, dout, B, N, H, delta, q_begin=0):
+    """``q_begin`` > 0 (here and in the two passes below): out / dout hold the query rows q_begin .. N - 1 of every clip compactly"""
     _chk(out, BF16, "out", 2), _chk(dout, BF16, "dout", 2), _chk(delta, F32, "delta")
-    if out.shape != (B * N, H * 64) or dout.shape != out.shape or delta.numel() != B * H * N:
+    if not 0 <= q_begin < N or out.shape != (B * (N - q_begin), H * 64) or dout.shape != out.shape or delta.numel() != B * H * N:
         raise ValueError("attention_delta: shape mismatch")
-    _run("mofo_attention_delta", ("attn_delta",), 4.0 * out.numel(), _p(out), _ld(out), _p(dout), _ld(dout), B, N, H, _p(delta))
+    _run("mofo_attention_delta_range", ("attn_delta",), 4.0 * out.numel(), _p(out), _ld(out), _p(dout), _ld(dout), B, N, H, q_begin, _p(delta))
 
 
-def attention_bwd_dq(qkv, dout, lse2, delta, B, N, H, scale, dqkv):
-    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta)
-    _run("mofo_attention_bwd_dq", ("attn_bwd_dq",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
-         B, N, H, scale, _p(dqkv), _ld(dqkv))
+def attention_bwd_dq(qkv, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
+    """dq rows below q_begin are NOT written (the caller clears them)"""
+    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta, q_begin)
+    _run("mofo_attention_bwd_dq_range", ("attn_bwd_dq",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
+         B, N, H, scale, q_begin, _p(dqkv), _ld(dqkv))
 
 
-def attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv):
-    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta)
-    _run("mofo_attention_bwd_dkv", ("attn_bwd_dkv",), 4.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
-         B, N, H, scale, _p(dqkv), _ld(dqkv))
+def attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
+    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta, q_begin)
+    _run("mofo_attention_bwd_dkv_range", ("attn_bwd_dkv",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
+         B, N, H, scale, q_begin, _p(dqkv), _ld(dqkv))
 
 
 def attention_delta_zero_dq(out, dout, B, N, H, delta, dqkv):

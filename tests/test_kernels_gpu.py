@@ -588,6 +588,59 @@ def test_attention_fwd_bwd(dev, B, N, H):
     assert torch.allclose(delta, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,N,H,qb", [(2, 1568, 2, 160), (1, 1561, 3, 168), (2, 224, 2, 40), (3, 100, 2, 32), (2, 160, 1, 16)])
+def test_attention_query_range(dev, B, N, H, qb):
+    """The *_range entries (queries q_begin .. N - 1 of every clip only, out / dout compact): what the last decoder block runs, whose
+    visible-token outputs feed nothing.  Forward rows and dq rows are those of the whole-sequence call bit for bit (the same key
+    loop per query, whatever tile the query lands in); dk / dv equal the whole-sequence backward with dO zeroed on the skipped
+    rows (dP = 0 and delta = 0 there, hence dS = 0); rows below q_begin of dq are left untouched; long (streaming), short (all
+    tiles staged at once) and ragged sequences, aligned and unaligned q_begin."""
+    from mofo_amd import ops
+    D = H * 64
+    scale = 64 ** -0.5
+    nq = N - qb
+    qkv = _rand((B * N, 3 * D), dev, 1, 1.5)
+    out = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
+    out_c = torch.full((B * nq, D), 7.0, dtype=BF16, device=dev)
+    lse_c = torch.full((B * H * N,), -5.0, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out_c, lse_c, q_begin=qb)
+    assert torch.equal(out_c.view(B, nq, D), out.view(B, N, D)[:, qb:])
+    assert torch.equal(lse_c.view(B, H, N)[:, :, qb:], lse2.view(B, H, N)[:, :, qb:])
+    assert torch.all(lse_c.view(B, H, N)[:, :, :qb] == -5.0)                      # nothing written for the skipped queries
+    dout = _rand((B * N, D), dev, 2)
+    dout.view(B, N, D)[:, :qb] = 0
+    dout_c = dout.view(B, N, D)[:, qb:].reshape(B * nq, D).contiguous()
+    # whole-sequence three-pass backward with dO = 0 on the skipped rows
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_delta(out, dout, B, N, H, delta)
+    ops.attention_bwd_dq(qkv, dout, lse2, delta, B, N, H, scale, dqkv)
+    ops.attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv)
+    # range backward
+    dq2 = torch.full_like(qkv, 3.0)
+    delta2 = torch.full((B * H * N,), 9.0, dtype=F32, device=dev)
+    ops.attention_delta(out_c, dout_c, B, N, H, delta2, q_begin=qb)
+    assert torch.equal(delta2.view(B, H, N)[:, :, qb:], delta.view(B, H, N)[:, :, qb:]) and torch.all(delta2.view(B, H, N)[:, :, :qb] == 9.0)
+    ops.attention_bwd_dq(qkv, dout_c, lse2, delta2, B, N, H, scale, dq2, q_begin=qb)
+    ops.attention_bwd_dkv(qkv, dout_c, lse2, delta2, B, N, H, scale, dq2, q_begin=qb)
+    a, b = dq2.view(B, N, 3 * D), dqkv.view(B, N, 3 * D)
+    assert torch.equal(a[:, qb:, :D], b[:, qb:, :D])                               # dq of the range
+    assert torch.all(a[:, :qb, :D] == 3.0)                                         # dq rows below q_begin untouched
+    for name, sl in (("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        # same products; with q_begin a multiple of 32 the query tiles coincide (only all-zero tiles are skipped: bit-identical),
+        # otherwise the queries group differently inside the MFMA reduction (f32 summation order: last-bit differences in bf16)
+        assert (torch.equal(a[:, :, sl], b[:, :, sl]) if qb % 32 == 0 else _rel(a[:, :, sl], b[:, :, sl]) < 3e-3), name
+    # and against fp32 torch
+    x = qkv.float().requires_grad_(True)
+    ref, _ = _attn_ref(x, B, N, H, scale)
+    ref.backward(dout.float())
+    for name, sl in (("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(a[:, :, sl], x.grad.view(B, N, 3 * D)[:, :, sl]) < 2e-2, name
+    assert _rel(a[:, qb:, :D], x.grad.view(B, N, 3 * D)[:, qb:, :D]) < 2e-2
+
+
 def test_attention_fwd_lazy_rescale_branch(dev, monkeypatch):
     """The forward kernel moves a row's reference maximum only when a tile's maximum exceeds it by more than
     MOFO_ATTN_RESCALE_THR log2 units (default 6).  Random data never takes that branch after the first tile, so the input
