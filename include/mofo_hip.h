@@ -54,7 +54,10 @@ typedef struct mofo_gemm_args {
     const void* aux; int ldaux;   /* DGELU: pre-activation h (bf16); RESID_BF16: the residual (bf16) */
     const float* pos; int ldpos;  /* POS_F32: table rows */
     const int* row_idx;           /* POS_F32: [M] table row per output row */
-    int rows_in, rows_out, row_off; /* POS_F32: out row = (m / rows_in) * rows_out + row_off + m % rows_in */
+    int rows_in, rows_out, row_off; /* POS_F32 / POS_BF16: out row = (m / rows_in) * rows_out + row_off + m % rows_in.
+                                     * RESID_F32 / RESID_BF16 with rows_in > 0 (M % rows_in == 0): the RESIDUAL operand's row of
+                                     * output row m is that expression (C itself stays dense) -- the last decoder block works on the masked
+                                     * tokens only while its residual input is the whole-sequence stream (modeling_pretrain.py:157) */
     int splits;                   /* split the reduction over gridDim.z (F32 epilogue only) */
     int accumulate;               /* F32 epilogue: add into C instead of overwrite */
     float* colsum;                /* TN + F32 only (wgrad): colsum[m] += sum_k A[k,m] = the bias gradient, fused; or NULL */
@@ -98,6 +101,13 @@ int mofo_layernorm_bwd(const void* dy_bf16, int lddy, const void* x, int x_is_bf
                        const void* dres_bf16, int lddres_bf16,
                        float* partial_ws /* >= 2 * mofo_layernorm_bwd_blocks(M) * D floats of scratch (2*1024*D always suffices), or NULL: NULL falls back to contended atomics */,
                        void* stream);
+/* The same with a PARTIAL residual gradient: of every group of dres_period rows only the rows t >= dres_skip carry one, stored
+ * compactly (row (r / period) * (period - skip) + r % period - skip of dres / dres_bf16); the others get none.  The decoder block
+ * below the last one: only its masked tokens were passed on (modeling_pretrain.py:157).  dres_period = 0: mofo_layernorm_bwd. */
+int mofo_layernorm_bwd_partial_res(const void* dy, int lddy, const void* x, int x_is_bf16, int ldx, const float* w, const float* mean,
+                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out, int row_off,
+                                   float* dx, int lddx, void* dx_bf16, int lddxb, float* dw, float* db, const void* dres_bf16, int lddres_bf16,
+                                   float* partial_ws, int dres_period, int dres_skip, void* stream);
 /* Deferred reduction: called with dw = db = NULL (and a partial_ws of its own) mofo_layernorm_bwd leaves only the
  * mofo_layernorm_bwd_blocks(M) block partials in partial_ws; mofo_layernorm_bwd_finalize adds the partials of up to 40
  * LayerNorms to their dw / db in one launch (34 per-LayerNorm reduction launches per ViT-B step become 1). */

@@ -43,6 +43,7 @@ _SIGS = {
     "mofo_fp8_quantize_bf16": (_i, [_vp, _ll, _vp, _vp, _vp, _vp]),
     "mofo_fp8_update_scales": (_i, [_vp, _vp, _i, _f, _vp]),
     "mofo_layernorm_bwd": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mofo_layernorm_bwd_partial_res": (_i, [_vp, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "mofo_layernorm_bwd_blocks": (_i, [_i]),
     "mofo_layernorm_bwd_finalize": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "mofo_attention_fwd": (_i, [_vp, _i, _i, _i, _i, _f, _vp, _i, _vp, _vp]),

@@ -166,6 +166,25 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
     constexpr int PROWS = WROWS / PASSES;       // ... staged per pass
     constexpr bool OUT_BF16 = (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16);
     constexpr bool AUX_ROWS = (EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16);   // a bf16 [M,N] operand read in the epilogue
+    // RESID_F32 / RESID_BF16 with rows_in > 0: the RESIDUAL operand's row of output row m is (m / rows_in) * rows_out + row_off +
+    // m % rows_in (the output itself is dense): the last decoder block runs on the masked tokens only, its residual input is the
+    // whole-sequence stream of the block before.  rows_in >= 256 (every real shape): one division per wave tile, which then crosses at
+    // most one group boundary; smaller groups (test geometries) divide per row.
+    constexpr bool RESID_MAP = (EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_RESID_BF16);
+    const bool rmap = RESID_MAP && p.rows_in > 0;
+    const int rm_seg0 = rmap ? mb / p.rows_in : 0;
+    const int rm_rem0 = rmap ? mb - rm_seg0 * p.rows_in : 0;
+    auto resid_row = [&](int m) -> size_t {
+        if constexpr (!RESID_MAP) return (size_t)m;
+        if (!rmap) return (size_t)m;
+        if (p.rows_in < 256) {
+            const int sg = m / p.rows_in;
+            return (size_t)sg * p.rows_out + p.row_off + (m - sg * p.rows_in);
+        }
+        const int rr = rm_rem0 + (m - mb);
+        const int wrap = rr >= p.rows_in ? 1 : 0;
+        return (size_t)(rm_seg0 + wrap) * p.rows_out + p.row_off + (rr - wrap * p.rows_in);
+    };
 
     auto stage_acc = [&](int ps) {
 #pragma unroll
@@ -267,7 +286,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                         // dGELU: the saved pre-activation is read here for the last time -- non-temporally, so that it does not push
                         // the gradient this kernel writes (and the next GEMM reads) out of the Infinity Cache
                         if constexpr (EPI == MOFO_EPI_DGELU_BF16 && MOFO_GEMM_NT_AUX) h[g] = __builtin_nontemporal_load((const u32x4*)(p.aux + (size_t)m * p.ldaux + n));
-                        else h[g] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                        else h[g] = *(const u32x4*)(p.aux + resid_row(m) * p.ldaux + n);
                     }
                 }
             }
@@ -356,7 +375,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                     for (int k = 0; k < CH; ++k) {
                         const int m = mb + (c * CH + k) * 4 + (lane >> 4);
                         dst[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (FULL || (ncol && m < p.M)) dst[k] = *(const f32x4*)(p.resid + (size_t)m * p.ldr + n);
+                        if (FULL || (ncol && m < p.M)) dst[k] = *(const f32x4*)(p.resid + resid_row(m) * p.ldr + n);
                     }
                 }
             };
@@ -1022,6 +1041,9 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
     if (epi == MOFO_EPI_DGELU_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: DGELU needs aux (ldaux multiple of 8)");
     if (epi == MOFO_EPI_RESID_BF16 && (!a->aux || a->ldaux % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: RESID_BF16 needs the bf16 residual in aux (ldaux multiple of 8)");
     if ((epi == MOFO_EPI_POS_F32 || epi == MOFO_EPI_POS_BF16) && (!a->pos || !a->row_idx || a->rows_in <= 0 || a->ldpos % 4)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: POS_F32 needs pos,row_idx,rows_in");
+    if ((epi == MOFO_EPI_RESID_F32 || epi == MOFO_EPI_RESID_BF16) && a->rows_in != 0 &&
+        (a->rows_in < 0 || a->rows_out < a->rows_in || a->row_off < 0 || a->row_off + a->rows_in > a->rows_out || a->M % a->rows_in))
+        MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: residual row map needs 0 < rows_in <= rows_out - row_off and M a multiple of rows_in");
     {
         // the operands are addressed through 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets):
         // an operand image of 2 GiB or more is refused instead of wrapping (split the rows / the reduction on the caller's side)

@@ -183,7 +183,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                                                       int lddres, int M, int D, int rows_in, int rows_out, int row_off,
                                                       float* __restrict__ dx, int lddx, bf16_t* __restrict__ dxb, int lddxb,
                                                       float* __restrict__ dw, float* __restrict__ db,
-                                                      const bf16_t* __restrict__ dresb, int lddresb, float* __restrict__ partial) {
+                                                      const bf16_t* __restrict__ dresb, int lddresb, float* __restrict__ partial,
+                                                      int dres_period, int dres_skip) {
+    // dres_period > 0: the residual gradient exists only for the rows t >= dres_skip of every group of dres_period rows and is
+    // stored COMPACTLY (row (r / period) * (period - skip) + r % period - skip); the other rows get no residual term.  The block
+    // below the last decoder block: only its masked tokens were passed on (modeling_pretrain.py:157).
     __shared__ float red[2][4][MAX_IT * 256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     f32x4 wv[NIT], aw[NIT], ab[NIT];
@@ -208,6 +212,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
             xr[k] = map_row(rr[k], rows_in, rows_out, row_off);
             mu[k] = mean[rr[k]];
             rs[k] = rstd[rr[k]];
+            size_t dr = xr[k];
+            bool has_res = true;
+            if (dres_period > 0) {
+                const int cl = rr[k] / dres_period, t = rr[k] - cl * dres_period;
+                has_res = t >= dres_skip;
+                dr = (size_t)cl * (dres_period - dres_skip) + (t - dres_skip);
+            }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int c = (it * 64 + lane) * 4;
@@ -220,10 +231,11 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const bf16_t* __restrict__ 
                     }
                     dv[k][it] = *(const u32x2*)(dy + (size_t)rr[k] * lddy + c);
                     if (dresb) {   // residual-stream gradient kept in bf16 (one tensor instead of an f32 + a bf16 copy)
-                        const u32x2 rb = *(const u32x2*)(dresb + xr[k] * lddresb + c);
+                        u32x2 rb = {0u, 0u};
+                        if (has_res) rb = *(const u32x2*)(dresb + dr * lddresb + c);
                         rv[k][it] = f32x4{bf16lo_to_f32(rb[0]), bf16hi_to_f32(rb[0]), bf16lo_to_f32(rb[1]), bf16hi_to_f32(rb[1])};
                     } else {
-                        rv[k][it] = dres ? *(const f32x4*)(dres + xr[k] * lddres + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        rv[k][it] = (dres && has_res) ? *(const f32x4*)(dres + dr * lddres + c) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
                 } else {
                     xv[k][it] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -466,6 +478,16 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const void* x, int x
                                   const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
                                   int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
                                   const void* dresb, int lddresb, float* partial_ws, void* stream) {
+    return mofo_layernorm_bwd_partial_res(dy, lddy, x, x_is_bf16, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx,
+                                          dxb, lddxb, dw, db, dresb, lddresb, partial_ws, 0, 0, stream);
+}
+
+extern "C" int mofo_layernorm_bwd_partial_res(const void* dy, int lddy, const void* x, int x_is_bf16, int ldx, const float* w, const float* mean,
+                                              const float* rstd, const float* dres, int lddres, int M, int D, int rows_in, int rows_out,
+                                              int row_off, float* dx, int lddx, void* dxb, int lddxb, float* dw, float* db,
+                                              const void* dresb, int lddresb, float* partial_ws, int dres_period, int dres_skip, void* stream) {
+    if (dres_period < 0 || (dres_period > 0 && (dres_skip < 0 || dres_skip >= dres_period || rows_in != rows_out || row_off != 0 || M % dres_period)))
+        MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: partial residual needs 0 <= dres_skip < dres_period, M a multiple of it and no row map");
     const bool defer = partial_ws && !dw && !db;      // block partials only; mofo_layernorm_bwd_finalize reduces them later
     if (!dy || !x || !w || !mean || !rstd || (!defer && (!dw || !db))) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: null pointer");
     if (!dx && !dxb) MOFO_FAIL(MOFO_EINVAL, "mofo_layernorm_bwd: need dx (f32) and/or dx_bf16");
@@ -480,7 +502,7 @@ extern "C" int mofo_layernorm_bwd(const void* dy, int lddy, const void* x, int x
     // at the encoder's M = 5120 while bounding the atomic traffic (1024 blocks x 2 D floats)
     const int blocks = mofo_layernorm_bwd_blocks(M);
     dim3 grid(blocks), block(256);
-#define GO_(N_, XB_) hipLaunchKernelGGL((ln_bwd_kernel<N_, XB_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws)
+#define GO_(N_, XB_) hipLaunchKernelGGL((ln_bwd_kernel<N_, XB_>), grid, block, 0, s, (const bf16_t*)dy, lddy, x, ldx, w, mean, rstd, dres, lddres, M, D, rows_in, rows_out, row_off, dx, lddx, (bf16_t*)dxb, lddxb, dw, db, (const bf16_t*)dresb, lddresb, partial_ws, dres_period, dres_skip)
 #define GO(N_) do { if (x_is_bf16) GO_(N_, true); else GO_(N_, false); } while (0)
     switch (nit) { case 1: GO(1); break; case 2: GO(2); break; case 3: GO(3); break; default: GO(4); break; }
 #undef GO_

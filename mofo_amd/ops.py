@@ -167,13 +167,17 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         _chk(C2, BF16, "C2", 2)
         if tuple(C2.shape) != (M, N):
             raise ValueError("C2 shape")
+    rmapped = epi in (EPI_RESID_F32, EPI_RESID_BF16) and rows_in > 0     # residual rows (m / rows_in) * rows_out + row_off + m % rows_in
+    rrows = ((M // rows_in - 1) * rows_out + row_off + rows_in) if rmapped else M
+    if rmapped and (M % rows_in or row_off < 0 or row_off + rows_in > rows_out):
+        raise ValueError("residual row map: M % rows_in == 0, row_off + rows_in <= rows_out")
     if epi == EPI_RESID_F32:
         _chk(resid, F32, "resid", 2)
-        if tuple(resid.shape) != (M, N):
+        if resid.shape[1] != N or (resid.shape[0] != M if not rmapped else resid.shape[0] < rrows):
             raise ValueError("resid shape")
     if epi in (EPI_DGELU_BF16, EPI_RESID_BF16):
         _chk(aux, BF16, "aux", 2)
-        if tuple(aux.shape) != (M, N):
+        if aux.shape[1] != N or (aux.shape[0] != M if not (rmapped and epi == EPI_RESID_BF16) else aux.shape[0] < rrows):
             raise ValueError("aux shape")
     if colsum is not None:
         _chk(colsum, F32, "colsum", 1)
@@ -292,9 +296,10 @@ def layernorm_bwd_blocks(M):
     return _lib.load().mofo_layernorm_bwd_blocks(int(M))
 
 
-def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None):
+def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=None, rows_out=None, row_off=0, partial_ws=None, dres_rows=None):
     """dx = dres + LN'(dy).  ``dres`` may be None, an f32 tensor or a bf16 tensor (shape of x); ``dx`` (f32) and ``dxb``
-    (bf16) are the outputs, either may be None but not both."""
+    (bf16) are the outputs, either may be None but not both.  ``dres_rows`` = (period, skip): the residual gradient covers only the
+    rows t >= skip of every group of period rows and is stored compactly ([M / period * (period - skip), D])."""
     if x is None or x.dtype not in (F32, BF16):
         raise TypeError("x must be f32 or bf16")
     _chk(dy, BF16, "dy", 2), _chk(x, x.dtype, "x", 2), _chk(w, F32, "w", 1)
@@ -314,7 +319,7 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
             dres_b = _chk(dres, BF16, "dres", 2)
         else:
             dres_f = _chk(dres, F32, "dres", 2)
-        if dres.shape != x.shape:
+        if dres_rows is None and dres.shape != x.shape:
             raise ValueError("dres shape")
     if dx is None and dxb is None:
         raise ValueError("layernorm_bwd: need dx and/or dxb")
@@ -334,13 +339,17 @@ def layernorm_bwd(dy, x, w, mean, rstd, dres, dx, dxb, dw, db, M=None, rows_in=N
         _chk(partial_ws, F32, "partial_ws", 1)
         if partial_ws.numel() < 2 * layernorm_bwd_blocks(M) * D:      # [blocks][2][D]; at most 1024 blocks
             raise ValueError("partial_ws must hold 2 * layernorm_bwd_blocks(M) * D floats (2*1024*D always suffices)")
+    period, skip = (0, 0) if dres_rows is None else (int(dres_rows[0]), int(dres_rows[1]))
+    if dres_rows is not None:
+        if dres is None or not 0 <= skip < period or M % period or rows_in != M or rows_out != M or row_off or tuple(dres.shape) != (M // period * (period - skip), D):
+            raise ValueError("layernorm_bwd: dres_rows = (period, skip) needs dres [M / period * (period - skip), D] and no row map")
     xb = 1 if x.dtype == BF16 else 0
     bytes_ = ((4.0 if xb else 6.0) + (4.0 if dres_f is not None else 0.0) + (2.0 if dres_b is not None else 0.0) + (4.0 if dx is not None else 0.0)
               + (2.0 if dxb is not None else 0.0)) * M * D
-    _run("mofo_layernorm_bwd", ("ln_bwd",), bytes_,
+    _run("mofo_layernorm_bwd_partial_res", ("ln_bwd",), bytes_,
          _p(dy), _ld(dy), _p(x), xb, _ld(x), _p(w), _p(mean), _p(rstd), _p(dres_f), _ld(dres_f) if dres_f is not None else 0, M, D,
          rows_in, rows_out, row_off, _p(dx), _ld(dx) if dx is not None else 0, _p(dxb), _ld(dxb) if dxb is not None else 0, _p(dw), _p(db),
-         _p(dres_b), _ld(dres_b) if dres_b is not None else 0, _p(partial_ws))
+         _p(dres_b), _ld(dres_b) if dres_b is not None else 0, _p(partial_ws), period, skip)
     return _lib.load().mofo_layernorm_bwd_blocks(M) if defer else None
 
 

@@ -405,6 +405,17 @@ class PretrainRuntime:
                   x_mid=e(M, D, dt=resid), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
                   x_out=e(M, D, dt=resid))
 
+    def _block_ws_last(self, M, Mc, D, H, B, n, resid=F32):
+        """workspace of the LAST decoder block when only the last ``Mc / B`` tokens of every clip are passed on (decoder.norm / head read
+        x[:, -return_token_num:], modeling_pretrain.py:157): LayerNorm 1, qkv, keys and values cover all M rows, everything behind the
+        attention (its output, proj, LayerNorm 2, the MLP, the block output) only the Mc rows that are read"""
+        dev = self.dev
+        hid = int(D * self.d.mlp_ratio)
+        e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
+        return NS(compact=True, xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), lse=e(B * H * n, dt=F32),
+                  ao=e(Mc, D), x_mid=e(Mc, D, dt=resid), xln2=e(Mc, D), mean2=e(Mc, dt=F32), rstd2=e(Mc, dt=F32), h1=e(Mc, hid), g=e(Mc, hid),
+                  x_out=e(Mc, D, dt=resid))
+
     def _scratch(self, M, D, H, B, n, group=1):
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
@@ -452,7 +463,18 @@ class PretrainRuntime:
             Md = B * N
             w.Md = Md
             w.x_full = e(B, N, d.dec_dim, dt=self.dec_resid)
-            w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N, self.dec_resid) for _ in range(d.dec_depth)]
+            # Dead work: the LAST decoder block's rows of the visible tokens feed nothing (only x[:, -return_token_num:] reaches
+            # decoder.norm / head, modeling_pretrain.py:157; the visible tokens are the first n_vis rows of a clip, :259).  With the
+            # full model (n_vis known here) that block works on the masked tokens only -- queries, proj, LayerNorm 2, MLP, their
+            # backward and weight-gradient reductions: 10 % of its rows at mask 0.9.  MOFO_DEC_LAST_COMPACT=0 keeps all rows.
+            w.dec_compact = (n_vis is not None and 0 < n_vis < N and d.dec_depth >= 1 and not getattr(self, "fp8", False)
+                             and os.environ.get("MOFO_DEC_LAST_COMPACT", "1") == "1")
+            w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N, self.dec_resid) for _ in range(d.dec_depth - (1 if w.dec_compact else 0))]
+            if w.dec_compact:
+                Mc = B * (N - n_vis)
+                w.dec.append(self._block_ws_last(Md, Mc, d.dec_dim, d.dec_heads, B, N, self.dec_resid))
+                hid = int(d.dec_dim * d.mlp_ratio)
+                w.dec_c = NS(dx0=e(Mc, d.dec_dim), dxln=e(Mc, d.dec_dim), dh1=e(Mc, hid), dxbB=e(Mc, d.dec_dim), dao=e(Mc, d.dec_dim))
             w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self.wgrad_blocks_dec)
             if n_vis is not None:
                 Mm = B * (N - n_vis)
@@ -520,6 +542,58 @@ class PretrainRuntime:
         else:
             ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
         return L.x_out
+
+    def _block_fwd_last(self, W, L, x_in, B, n, H, qb):
+        """the last decoder block on the tokens that are read (rows qb .. n - 1 of every clip): keys / values from all rows, queries and
+        everything behind the attention from those rows only; the residual input is read through the GEMM's residual row map"""
+        eps, scale = self.d.eps, 64 ** -0.5
+        ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
+        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
+        ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse, q_begin=qb)
+        rmap = dict(rows_in=n - qb, rows_out=n, row_off=qb)
+        if L.x_mid.dtype == BF16:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.ao, W.proj, L.x_mid, bias=W.projb, aux=x_in, **rmap)
+        else:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in, **rmap)
+        ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
+        ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
+        if L.x_out.dtype == BF16:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.g, W.fc2, L.x_out, bias=W.fc2b, aux=L.x_mid)
+        else:
+            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
+        return L.x_out
+
+    def _block_bwd_last(self, W, L, S, C, x_in, B, n, H, qb, flush=False):
+        """backward of _block_fwd_last (always the first block of a decoder backward pass: scratch set 0, ring 0 -> 1).  The gradient
+        wrt the block output arrives compact in ``C.dx0``; the gradient wrt the block INPUT covers all rows again (keys / values and
+        LayerNorm 1 saw them) and lands in ``S.ring[1]``; the residual term exists for the rows qb .. n - 1 only (partial-residual
+        LayerNorm backward).  The dq rows of the skipped queries are cleared: the qkv dgrad and weight gradient read all rows."""
+        scale = 64 ** -0.5
+        D = x_in.shape[1]
+        R = len(S.ring)
+        T = S.sets[0]
+        dxb_in = S.ring[1 % R]
+        slot = S.gidx % 2
+        if S.gcount == 0 and S.used[slot]:
+            ops.host_op(lambda ev=S.done[slot]: torch.cuda.current_stream().wait_event(ev))
+            S.used[slot] = False
+        ops.gemm(ops.GEMM_NN, ops.EPI_DGELU_BF16, C.dx0, W.fc2, C.dh1, aux=L.h1)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dh1, W.fc1, C.dxln)
+        self._ln_bwd(C.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, C.dx0, None, C.dxbB, W.g_ln2w, W.g_ln2b)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dxbB, W.proj, C.dao)
+        ops.attention_delta(L.ao, C.dao, B, n, H, S.delta, q_begin=qb)
+        dq_dead = T.dqkv.view(B, n, 3 * D)[:, :qb, :D]
+        ops.host_op(lambda: dq_dead.zero_())
+        ops.attention_bwd_dkv(L.qkv, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
+        ops.attention_bwd_dq(L.qkv, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
+        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
+        self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, C.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b, dres_rows=(n, qb))
+        S.pending += [(C.dx0, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (C.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
+                      (C.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
+        S.gcount += 1
+        if S.gcount == S.group or flush:
+            self._wgrad_flush(S, slot, n)
+            S.gidx, S.gcount = S.gidx + 1, 0
 
     def _wgrad(self, dY, X, G, bias_grad=None):
         """dW (+)= dY^T X, and the bias gradient db += colsum(dY) fused into the same launch"""
@@ -839,10 +913,19 @@ class PretrainRuntime:
         predictions [B*n_ret, patch_out]."""
         d, s, p = self.d, self.store, self.dec_prefix
         x = x_full.view(w.Md, d.dec_dim)
-        for W, L in zip(self.decW, w.dec):
-            x = self._block_fwd(W, L, x, w.B, w.N, d.dec_heads)
-        ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.dec_ln, w.dec_mean, w.dec_rstd,
-                          rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        compact = getattr(w, "dec_compact", False) and n_ret == w.n_msk
+        for i, (W, L) in enumerate(zip(self.decW, w.dec)):
+            if getattr(L, "compact", False):
+                if not compact:
+                    raise ValueError("this workspace's last decoder block keeps the masked tokens only: return_token_num must be their count")
+                x = self._block_fwd_last(W, L, x, w.B, w.N, d.dec_heads, w.N - n_ret)
+            else:
+                x = self._block_fwd(W, L, x, w.B, w.N, d.dec_heads)
+        if compact:      # the last block's output holds exactly the rows decoder.norm / head read
+            ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.dec_ln, w.dec_mean, w.dec_rstd)
+        else:
+            ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.dec_ln, w.dec_mean, w.dec_rstd,
+                              rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, w.dec_ln, s.bview(p + "head.weight"), w.pred, bias=s.view(p + "head.bias"))
         return w.pred
 
@@ -853,14 +936,24 @@ class PretrainRuntime:
         S.used, S.gidx, S.gcount = [False, False], 0, 0
         # the head's weight gradient (36 tiles) joins the first decoder block's grouped launch on the side stream
         S.pending.append((dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"), (0, 0)))
-        # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
-        # (only those rows: the LayerNorm backward below writes the other n_ret rows of every clip)
-        head_zero = S.ring[0].view(w.B, w.N, d.dec_dim)[:, :w.N - n_ret]
-        ops.host_op(lambda: head_zero.zero_())
-        self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
-                     s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        compact = bool(w.dec) and getattr(w.dec[-1], "compact", False)
         j = 0
-        for i in range(d.dec_depth - 1, -1, -1):
+        top = d.dec_depth - 1
+        if compact:
+            # the last block's rows of the visible tokens do not exist: everything down to its attention stays on the n_ret rows
+            self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, w.dec_c.dx0,
+                         s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
+            x_in = w.dec[top - 1].x_out if top > 0 else x_full.view(w.Md, d.dec_dim)
+            self._block_bwd_last(self.decW[top], w.dec[top], S, w.dec_c, x_in, w.B, w.N, d.dec_heads, w.N - n_ret, flush=(top == 0))
+            j, top = 1, top - 1
+        else:
+            # rows of the visible tokens get no gradient from the head (x[:, -n_ret:], modeling_pretrain.py:157)
+            # (only those rows: the LayerNorm backward below writes the other n_ret rows of every clip)
+            head_zero = S.ring[0].view(w.B, w.N, d.dec_dim)[:, :w.N - n_ret]
+            ops.host_op(lambda: head_zero.zero_())
+            self._ln_bwd(w.d_decln, x_last, s.view(p + "norm.weight"), w.dec_mean, w.dec_rstd, None, None, S.ring[0],
+                         s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
+        for i in range(top, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
             self._block_bwd(self.decW[i], w.dec[i], S, j, x_in, w.B, w.N, d.dec_heads, flush=(i == 0))
             j += 1

@@ -398,6 +398,63 @@ def test_gemm_k2_one_tile_per_cu_family(dev, monkeypatch, M, N, K, stag):
         assert torch.equal(Cb, first)
 
 
+@pytest.mark.parametrize("Bc,n_all,skip,N,K", [(3, 40, 16, 192, 128), (2, 1568, 160, 384, 384), (4, 300, 44, 768, 1536), (32, 160, 24, 128, 64)])
+def test_gemm_residual_row_map(dev, Bc, n_all, skip, N, K):
+    """RESID_F32 / RESID_BF16 with a residual ROW MAP (rows_in > 0): the output is dense over the n_all - skip kept rows of each of
+    Bc groups, the residual operand is the whole-sequence tensor (row (m / rows_in) * rows_out + row_off + m % rows_in) -- the last
+    decoder block's proj GEMM.  Small groups (per-row division), the ViT-B decoder's 1408-of-1568 (one division per wave tile,
+    tiles that straddle a group boundary), and a shape the one-tile-per-CU kernel takes (K = 1536, 1024 x 768)."""
+    from mofo_amd import ops
+    keep = n_all - skip
+    M = Bc * keep
+    A = _rand((M, K), dev, 1)
+    W = _rand((N, K), dev, 2, 0.05)
+    bias = _rand((N,), dev, 3, 1.0, F32)
+    R = _rand((Bc * n_all, N), dev, 4, 1.0, F32)
+    want = A.float() @ W.float().t() + bias + R.view(Bc, n_all, N)[:, skip:].reshape(M, N)
+    Cf = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, W, Cf, bias=bias, resid=R, rows_in=keep, rows_out=n_all, row_off=skip)
+    assert _rel(Cf, want) < 2e-3 and ((Cf - want).abs() > 0.05 * want.abs().max()).sum().item() == 0
+    Rb = R.to(BF16)
+    wantb = A.float() @ W.float().t() + bias + Rb.float().view(Bc, n_all, N)[:, skip:].reshape(M, N)
+    Cb = torch.empty(M, N, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, A, W, Cb, bias=bias, aux=Rb, rows_in=keep, rows_out=n_all, row_off=skip)
+    assert _rel(Cb, wantb) < 6e-3 and ((Cb.float() - wantb).abs() > 0.05 * wantb.abs().max()).sum().item() == 0
+    with pytest.raises(ValueError):
+        ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, A, W, Cf, bias=bias, resid=R, rows_in=keep, rows_out=n_all, row_off=skip + 1)
+
+
+@pytest.mark.parametrize("Bc,n_all,skip,D,xb", [(3, 40, 16, 384, True), (2, 1568, 160, 384, True), (5, 33, 1, 768, False)])
+def test_layernorm_bwd_partial_residual(dev, Bc, n_all, skip, D, xb):
+    """LayerNorm backward whose residual gradient exists for the rows t >= skip of every group of n_all rows only, stored compactly
+    (the block below the last decoder block: only its masked tokens were passed on): equals the dense call with zeros on the other rows"""
+    from mofo_amd import ops
+    M = Bc * n_all
+    x = _rand((M, D), dev, 1, 2.0, F32) + 0.5
+    if xb:
+        x = x.to(BF16)
+    w = _rand((D,), dev, 2, 0.3, F32) + 1.0
+    b = _rand((D,), dev, 3, 0.3, F32)
+    y = torch.empty(M, D, dtype=BF16, device=dev)
+    mean, rstd = torch.empty(M, dtype=F32, device=dev), torch.empty(M, dtype=F32, device=dev)
+    ops.layernorm_fwd(x, w, b, 1e-6, y, mean, rstd)
+    dy = _rand((M, D), dev, 4)
+    dres_c = _rand((Bc * (n_all - skip), D), dev, 5)
+    dense = torch.zeros(M, D, dtype=BF16, device=dev)
+    dense.view(Bc, n_all, D)[:, skip:] = dres_c.view(Bc, n_all - skip, D)
+    ws = torch.empty(2 * 1024 * D, dtype=F32, device=dev)
+    outs = []
+    for kw, dr in ((dict(), dense), (dict(dres_rows=(n_all, skip)), dres_c)):
+        dxb = torch.empty(M, D, dtype=BF16, device=dev)
+        dw, db = torch.zeros(D, dtype=F32, device=dev), torch.zeros(D, dtype=F32, device=dev)
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dr, None, dxb, dw, db, partial_ws=ws, **kw)
+        outs.append((dxb, dw, db))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.allclose(outs[0][1], outs[1][1], rtol=1e-5, atol=1e-5) and torch.allclose(outs[0][2], outs[1][2], rtol=1e-5, atol=1e-5)   # (finalize adds atomically)
+    with pytest.raises(ValueError):
+        ops.layernorm_bwd(dy, x, w, mean, rstd, dres_c, None, dxb, dw, db, partial_ws=ws, dres_rows=(n_all + 1, skip))
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from mofo_amd import ops
     A = _rand((64, 96), dev, 1)
