@@ -207,6 +207,16 @@ int mofo_patch_gather(const float* clips, int B, int C, int T, int H, int W, int
  * x_full[b, n_vis + j] = mask_token + pos[msk_idx[b,j]]  (the visible half is the e2d GEMM's POS_F32 / POS_BF16 epilogue). ---- */
 int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx,
                           int B, int N, int n_vis, int D, void* x_full, int x_is_bf16, void* stream);
+/* ---- decoder block 0, shared masked rows.  Its input rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262):
+ * they depend on the position only, and so do their LayerNorm-1 and qkv rows (modeling_finetune.py:216-219).  A caller computes those
+ * once per position next to the visible rows -- "cat" layout [B * n_vis visible rows | N position rows] x W bf16 -- and
+ *   mofo_dec0_gather : full[b, r] = r < n_vis ? cat[b * n_vis + r] : cat[B * n_vis + msk_idx[b, r - n_vis]]      ([B * N, W])
+ *   mofo_dec0_reduce : its adjoint for gradients (visible rows copied, position rows = f32 sum over the clips that mask that position)
+ *   mofo_dec0_inverse: inv[b, j] = slot of position j in clip b's ASCENDING masked list (as mofo_mask_to_indices writes it), or -1
+ *                      (what mofo_dec0_reduce reads). ---- */
+int mofo_dec0_inverse(const int* msk_idx, int B, int N, int n_vis, int* inv, void* stream);
+int mofo_dec0_gather(const void* cat, int ldcat, const int* msk_idx, int B, int N, int n_vis, int W, void* full, int ldfull, void* stream);
+int mofo_dec0_reduce(const void* full, int ldfull, const int* inv, int B, int N, int n_vis, int W, void* cat, int ldcat, void* stream);
 /* backward of the assembly: d_e2d(bf16)[b*n_vis + j] = dx_full[b, j];  d_mask_token[d] += sum over masked rows.
  * dx_full is f32 (dx_is_bf16 = 0) or bf16 (1).  partial_ws: mofo_assemble_bwd_blocks(B, N) * D floats of scratch for the
  * blocks' column sums (a second small launch adds them), or NULL: every block then adds to d_mask_token with atomics

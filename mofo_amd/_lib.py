@@ -62,6 +62,9 @@ _SIGS = {
     "mofo_tube_masks": (_i, [C.c_uint, C.c_uint, _i, _i, _i, _i, _vp, _vp]),
     "mofo_patch_gather": (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp]),
     "mofo_fill_mask_tokens": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mofo_dec0_inverse": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "mofo_dec0_gather": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
+    "mofo_dec0_reduce": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "mofo_assemble_bwd_blocks": (_i, [_i, _i]),
     "mofo_assemble_bwd": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mofo_assemble_bwd_finalize": (_i, [_vp, _i, _i, _i, _vp, _vp]),

@@ -427,7 +427,7 @@ extern "C" int mofo_patch_gather_u8(const uint8_t* frames, int B, int T, int H, 
 extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, int ldpos, const int* msk_idx, int B, int N,
                                      int n_vis, int D, void* x_full, int x_is_bf16, void* stream) {
     if (!mask_token || !pos || !msk_idx || !x_full) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: null pointer");
-    if (B <= 0 || N <= n_vis || n_vis <= 0 || D <= 0 || D % 4 || ldpos % 4) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: bad sizes");
+    if (B <= 0 || N <= n_vis || n_vis < 0 || D <= 0 || D % 4 || ldpos % 4) MOFO_FAIL(MOFO_EINVAL, "mofo_fill_mask_tokens: bad sizes");
     const int rows = B * (N - n_vis);
     if (x_is_bf16)
         hipLaunchKernelGGL(fill_mask_kernel<true>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
@@ -436,6 +436,119 @@ extern "C" int mofo_fill_mask_tokens(const float* mask_token, const float* pos, 
         hipLaunchKernelGGL(fill_mask_kernel<false>, dim3(ceil_div(rows, 4)), dim3(256), 0, (hipStream_t)stream, mask_token, pos, ldpos,
                            msk_idx, N, n_vis, D, rows, x_full);
     MOFO_CHECK_LAUNCH("mofo_fill_mask_tokens");
+    return MOFO_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- decoder block 0: shared masked rows
+// In the FIRST decoder block the input rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262): they depend
+// on the POSITION j only, not on the clip, and so do their LayerNorm-1 and qkv rows.  The runtime computes those once per position
+// (N rows) beside the B * n_vis visible rows ("cat" layout: [B * n_vis visible rows | N position rows]) and
+//   * dec0_gather spreads them to the whole-sequence layout the attention kernels read:
+//       full[b, r] = r < n_vis ? cat[b * n_vis + r] : cat[B * n_vis + msk_idx[b, r - n_vis]]
+//   * dec0_reduce is its adjoint for the qkv gradient:  cat[b * n_vis + r] = full[b, r];
+//       cat[B * n_vis + j] = sum over the clips b in which position j is masked of full[b, n_vis + slot_b(j)]   (f32 sum, one rounding)
+//     with slot_b(j) from the inverse table dec0_inverse builds (inv[b, j] = slot or -1).  No atomics: one thread per (row, 16-B chunk).
+namespace {
+// one thread per (clip, position): binary search in the clip's ASCENDING masked list (what mofo_mask_to_indices writes) -- every entry
+// of inv is written by exactly one thread, nothing to clear first
+__global__ __launch_bounds__(256) void dec0_inverse_kernel(const int* __restrict__ msk_idx, int n_msk, int N, int total, int* __restrict__ inv) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int b = i / N, j = i - b * N;
+    const int* row = msk_idx + (size_t)b * n_msk;
+    int lo = 0, hi = n_msk;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (row[mid] < j) lo = mid + 1;
+        else hi = mid;
+    }
+    inv[i] = (lo < n_msk && row[lo] == j) ? lo : -1;
+}
+
+__global__ __launch_bounds__(256) void dec0_gather_kernel(const bf16_t* __restrict__ cat, int ldcat, const int* __restrict__ msk_idx, int B, int N,
+                                                          int n_vis, int cpr, bf16_t* __restrict__ full, int ldfull) {
+    const long long total = (long long)B * N * cpr;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        const int row = (int)(id / cpr), c = (int)(id - (long long)row * cpr);
+        const int b = row / N, r = row - b * N;
+        const int src = r < n_vis ? b * n_vis + r : B * n_vis + msk_idx[(size_t)b * (N - n_vis) + (r - n_vis)];
+        *(u32x4*)(full + (size_t)row * ldfull + c * 8) = *(const u32x4*)(cat + (size_t)src * ldcat + c * 8);
+    }
+}
+
+__global__ __launch_bounds__(256) void dec0_reduce_kernel(const bf16_t* __restrict__ full, int ldfull, const int* __restrict__ inv, int B, int N,
+                                                          int n_vis, int cpr, bf16_t* __restrict__ cat, int ldcat) {
+    const long long vis_chunks = (long long)B * n_vis * cpr, total = vis_chunks + (long long)N * cpr;
+    for (long long id = (long long)blockIdx.x * 256 + threadIdx.x; id < total; id += (long long)gridDim.x * 256) {
+        if (id < vis_chunks) {
+            const int row = (int)(id / cpr), c = (int)(id - (long long)row * cpr);
+            const int b = row / n_vis, r = row - b * n_vis;
+            *(u32x4*)(cat + (size_t)row * ldcat + c * 8) = *(const u32x4*)(full + ((size_t)b * N + r) * ldfull + c * 8);
+        } else {
+            const long long q = id - vis_chunks;
+            const int j = (int)(q / cpr), c = (int)(q - (long long)j * cpr);
+            float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            // eight clips per round: the eight slot loads, then the eight row loads are independent (a thread's latency chain is
+            // B / 8 * 2 round trips instead of 2 B); the sum runs in clip order whatever the grouping
+            for (int b0 = 0; b0 < B; b0 += 8) {
+                int slot[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) slot[u] = b0 + u < B ? inv[(size_t)(b0 + u) * N + j] : -1;
+                u32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = slot[u] >= 0 ? *(const u32x4*)(full + ((size_t)(b0 + u) * N + n_vis + slot[u]) * ldfull + c * 8) : u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        acc[2 * e] += bf16lo_to_f32(v[u][e]);
+                        acc[2 * e + 1] += bf16hi_to_f32(v[u][e]);
+                    }
+            }
+            *(u32x4*)(cat + ((size_t)B * n_vis + j) * ldcat + c * 8) =
+                u32x4{pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+        }
+    }
+}
+}  // namespace
+
+static int dec0_check(const char* who, int B, int N, int n_vis, int W, int lda, int ldb) {
+    if (B <= 0 || N <= 0 || n_vis <= 0 || n_vis >= N) MOFO_FAIL(MOFO_EINVAL, "%s: need 0 < n_vis < N and B > 0", who);
+    if (W <= 0 || W % 8 || lda % 8 || ldb % 8 || lda < W || ldb < W) MOFO_FAIL(MOFO_EUNSUPPORTED, "%s: row width and leading dims must be multiples of 8", who);
+    return MOFO_OK;
+}
+
+extern "C" int mofo_dec0_inverse(const int* msk_idx, int B, int N, int n_vis, int* inv, void* stream) {
+    if (!msk_idx || !inv) MOFO_FAIL(MOFO_EINVAL, "mofo_dec0_inverse: null pointer");
+    if (B <= 0 || N <= 0 || n_vis <= 0 || n_vis >= N) MOFO_FAIL(MOFO_EINVAL, "mofo_dec0_inverse: need 0 < n_vis < N and B > 0");
+    const int total = B * N;
+    hipLaunchKernelGGL(dec0_inverse_kernel, dim3(ceil_div(total, 256)), dim3(256), 0, (hipStream_t)stream, msk_idx, N - n_vis, N, total, inv);
+    MOFO_CHECK_LAUNCH("mofo_dec0_inverse");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_dec0_gather(const void* cat, int ldcat, const int* msk_idx, int B, int N, int n_vis, int W, void* full, int ldfull, void* stream) {
+    if (!cat || !msk_idx || !full) MOFO_FAIL(MOFO_EINVAL, "mofo_dec0_gather: null pointer");
+    int rc = dec0_check("mofo_dec0_gather", B, N, n_vis, W, ldcat, ldfull);
+    if (rc) return rc;
+    const long long total = (long long)B * N * (W / 8);
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(dec0_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)cat, ldcat, msk_idx, B, N, n_vis, W / 8,
+                       (bf16_t*)full, ldfull);
+    MOFO_CHECK_LAUNCH("mofo_dec0_gather");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_dec0_reduce(const void* full, int ldfull, const int* inv, int B, int N, int n_vis, int W, void* cat, int ldcat, void* stream) {
+    if (!full || !inv || !cat) MOFO_FAIL(MOFO_EINVAL, "mofo_dec0_reduce: null pointer");
+    int rc = dec0_check("mofo_dec0_reduce", B, N, n_vis, W, ldcat, ldfull);
+    if (rc) return rc;
+    const long long total = ((long long)B * n_vis + N) * (W / 8);
+    const int blocks = (int)(total / 256 + 1 < 8192 ? total / 256 + 1 : 8192);
+    hipLaunchKernelGGL(dec0_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)full, ldfull, inv, B, N, n_vis, W / 8,
+                       (bf16_t*)cat, ldcat);
+    MOFO_CHECK_LAUNCH("mofo_dec0_reduce");
     return MOFO_OK;
 }
 

@@ -509,6 +509,36 @@ def fill_mask_tokens(mask_token, pos, msk_idx, n_vis, x_full):
          _p(x_full), xb)
 
 
+def dec0_inverse(msk_idx, N, inv):
+    """inv[b, j] = slot of position j in clip b's ascending masked list (msk_idx [B, n_msk]) or -1"""
+    _chk(msk_idx, I32, "msk_idx", 2), _chk(inv, I32, "inv", 2)
+    B, n_msk = msk_idx.shape
+    if not msk_idx.is_contiguous() or not inv.is_contiguous() or inv.shape != (B, N) or not 0 < n_msk < N:
+        raise ValueError("dec0_inverse: msk_idx [B, n_msk], inv [B, N]")
+    _run("mofo_dec0_inverse", ("dec0_idx",), 8.0 * B * N, _p(msk_idx), B, N, N - n_msk, _p(inv))
+
+
+def dec0_gather(cat, msk_idx, N, full):
+    """full[b, r] = r < n_vis ? cat[b * n_vis + r] : cat[B * n_vis + msk_idx[b, r - n_vis]] (bf16 rows; include/mofo_hip.h)"""
+    _chk(cat, BF16, "cat", 2), _chk(full, BF16, "full", 2), _chk(msk_idx, I32, "msk_idx", 2)
+    B, n_msk = msk_idx.shape
+    n_vis = N - n_msk
+    if cat.shape[0] != B * n_vis + N or full.shape != (B * N, cat.shape[1]) or not msk_idx.is_contiguous():
+        raise ValueError("dec0_gather: cat [B * n_vis + N, W], full [B * N, W]")
+    _run("mofo_dec0_gather", ("dec0_gather",), 4.0 * full.numel(), _p(cat), _ld(cat), _p(msk_idx), B, N, n_vis, cat.shape[1], _p(full), _ld(full))
+    return full
+
+
+def dec0_reduce(full, inv, n_vis, cat):
+    """adjoint of dec0_gather: visible rows copied, position rows summed over the clips that mask the position"""
+    _chk(cat, BF16, "cat", 2), _chk(full, BF16, "full", 2), _chk(inv, I32, "inv", 2)
+    B, N = inv.shape
+    if cat.shape[0] != B * n_vis + N or full.shape != (B * N, cat.shape[1]) or not inv.is_contiguous():
+        raise ValueError("dec0_reduce: cat [B * n_vis + N, W], full [B * N, W]")
+    _run("mofo_dec0_reduce", ("dec0_reduce",), 2.0 * full.numel() + 2.0 * cat.numel(), _p(full), _ld(full), _p(inv), B, N, n_vis, cat.shape[1], _p(cat), _ld(cat))
+    return cat
+
+
 def assemble_bwd_blocks(B, N):
     return _lib.load().mofo_assemble_bwd_blocks(B, N)
 

@@ -476,6 +476,19 @@ class PretrainRuntime:
                 hid = int(d.dec_dim * d.mlp_ratio)
                 w.dec_c = NS(dx0=e(Mc, d.dec_dim), dxln=e(Mc, d.dec_dim), dh1=e(Mc, hid), dxbB=e(Mc, d.dec_dim), dao=e(Mc, d.dec_dim))
             w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self.wgrad_blocks_dec)
+            # Shared work: in the FIRST decoder block the rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262)
+            # -- a function of the position alone, and so are their LayerNorm 1 and qkv rows.  With the full model LayerNorm 1, the qkv
+            # GEMM, its dgrad, the LayerNorm backward and the qkv weight-gradient reduction run on [B * n_vis visible rows | N position
+            # rows] ("cat" rows: 6 688 instead of 50 176 at ViT-B, B = 32) and ops.dec0_gather / dec0_reduce move between the two
+            # layouts.  MOFO_DEC0_SHARE=0 computes all rows.
+            w.dec_share = (w.dec_compact and d.dec_depth >= 2 and self.top and self.enc_prefix is not None and self.dec_resid == BF16
+                           and d.dec_dim % 8 == 0 and os.environ.get("MOFO_DEC0_SHARE", "1") == "1")
+            if w.dec_share:
+                Mc, Dd = B * n_vis + N, d.dec_dim
+                w.dec0 = NS(xcat=e(Mc, Dd), xln1=e(Mc, Dd), mean1=e(Mc, dt=F32), rstd1=e(Mc, dt=F32), qkv=e(Mc, 3 * Dd),
+                            inv=torch.zeros(B, N, dtype=I32, device=dev), pos_idx=torch.arange(N, dtype=I32, device=dev).view(1, N),
+                            dqkv=e(Mc, 3 * Dd), dres=e(Mc, Dd), dxln=e(Mc, Dd), dxcat=e(Mc, Dd), msk_idx=w.msk_idx, n_vis=n_vis, N=N)
+                w.dec[0].xln1 = w.dec[0].mean1 = w.dec[0].rstd1 = None      # block 0 keeps these per cat row (w.dec0)
             if n_vis is not None:
                 Mm = B * (N - n_vis)
                 w.Mm = Mm
@@ -515,10 +528,16 @@ class PretrainRuntime:
             ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
 
     # ------------------------------------------------------------------ transformer block
-    def _block_fwd(self, W, L, x_in, B, n, H):
+    def _block_fwd(self, W, L, x_in, B, n, H, share=None):
+        """``share`` (the first decoder block of the full model, see ``ws``): LayerNorm 1 and the qkv GEMM run once per cat row"""
         eps, scale = self.d.eps, 64 ** -0.5
         f8 = self.fp8 and getattr(W, "qkv8", None) is not None and hasattr(L, "xln1_8")
-        if f8:
+        if share is not None:
+            Z = share
+            ops.layernorm_fwd(Z.xcat, W.ln1w, W.ln1b, eps, Z.xln1, Z.mean1, Z.rstd1)
+            ops.gemm(ops.GEMM_NT, ops.EPI_BF16, Z.xln1, W.qkv, Z.qkv, bias=W.qkvb)
+            ops.dec0_gather(Z.qkv, Z.msk_idx, Z.N, L.qkv)
+        elif f8:
             sc, am = self.act_scales, self.act_amax
             ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[W.site, 0:1], am[W.site])
             ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, L.xln1_8, W.qkv8, L.qkv, bias=W.qkvb, a_scale_inv=sc[W.site, 1:2], b_scale_inv=W.qkv8_si)
@@ -628,7 +647,7 @@ class PretrainRuntime:
                          [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
                           for dY, X, G, bg, skip in problems])
 
-    def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False, hold=False):
+    def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False, hold=False, share=None):
         """Backward of the j-th block of a backward pass (j = 0 for the top block).  Reads the gradient wrt the block output
         from ``S.ring[j % R]`` (bf16), writes the gradient wrt its input to ``S.ring[(j + 1) % R]``.  The block's weight
         gradients are DEFERRED: they join the pending group, which is launched on the side stream once it holds ``S.group``
@@ -680,12 +699,24 @@ class PretrainRuntime:
                 ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
                 ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
                 ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-        ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
-        self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
+        if share is not None:
+            # the adjoint of the forward's row sharing: qkv gradient and residual gradient summed per cat row (visible rows copied,
+            # position rows added over the clips that mask the position, f32), then dgrad / LayerNorm backward / weight gradient on
+            # those rows; the result is the gradient wrt the CAT rows of the decoder input (bridge_backward reads it as such)
+            Z = share
+            ops.dec0_reduce(T.dqkv, Z.inv, Z.n_vis, Z.dqkv)
+            ops.dec0_reduce(T.dxbB, Z.inv, Z.n_vis, Z.dres)
+            ops.gemm(ops.GEMM_NN, ops.EPI_BF16, Z.dqkv, W.qkv, Z.dxln)
+            self._ln_bwd(Z.dxln, Z.xcat, W.ln1w, Z.mean1, Z.rstd1, Z.dres, None, Z.dxcat, W.g_ln1w, W.g_ln1b)
+            qkv_grad = (Z.dqkv, Z.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))
+        else:
+            ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
+            self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, T.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b)
+            qkv_grad = (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))
         # parameter gradients of the whole block (weights + biases; the bias gradients are column sums of the same dY
         # operands, fused into the GEMMs): one grouped launch on the SIDE stream, off the activation-gradient chain
         S.pending += [(dxb_out, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (T.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
-                      (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), (T.dqkv, L.xln1, W.g_qkv, W.g_qkvb, (D, 2 * D))]
+                      (T.dxbB, L.ao, W.g_proj, W.g_projb, (0, 0)), qkv_grad]
         S.gcount += 1
         if (S.gcount == G or flush) and not hold:      # hold: the caller adds one more problem to this group and flushes it
             self._wgrad_flush(S, slot, n)
@@ -879,6 +910,16 @@ class PretrainRuntime:
     def bridge_forward(self, w: NS, enc_out_bf16: torch.Tensor):
         """modeling_pretrain.py:256-263: encoder_to_decoder (no bias) + pos for the visible half, mask_token + pos for the rest."""
         d, s = self.d, self.store
+        if getattr(w, "dec_share", False):
+            # cat rows: the visible tokens' rows clip by clip, then ONE row per position (mask_token + pos[j]); the whole-sequence
+            # input the decoder's residual path reads is gathered from them (bit-identical to writing every row on its own)
+            Z = w.dec0
+            ops.gemm(ops.GEMM_NT, ops.EPI_POS_BF16, enc_out_bf16, s.bview("encoder_to_decoder.weight"), Z.xcat[:w.Me],
+                     pos=self.pos_dec, row_idx=w.vis_idx.view(-1), rows_in=w.Me, rows_out=w.Me)
+            ops.fill_mask_tokens(s.view("mask_token").view(-1), self.pos_dec, Z.pos_idx, 0, Z.xcat[w.Me:].view(1, w.N, d.dec_dim))
+            ops.dec0_gather(Z.xcat, w.msk_idx, w.N, w.x_full.view(w.Md, d.dec_dim))
+            ops.dec0_inverse(w.msk_idx, w.N, Z.inv)
+            return w.x_full
         ops.gemm(ops.GEMM_NT, ops.EPI_POS_BF16 if w.x_full.dtype == BF16 else ops.EPI_POS_F32, enc_out_bf16,
                  s.bview("encoder_to_decoder.weight"), w.x_full.view(w.Md, d.dec_dim),
                  pos=self.pos_dec, row_idx=w.vis_idx.view(-1), rows_in=w.n_vis, rows_out=w.N, row_off=0)
@@ -888,6 +929,14 @@ class PretrainRuntime:
     def bridge_backward(self, w: NS, dx_full: torch.Tensor, enc_out_bf16: torch.Tensor):
         d, s = self.d, self.store
         gmask = s.gview("mask_token").view(-1)
+        if getattr(w, "dec_share", False):
+            # dx_full holds the gradient per CAT row: the visible rows are d(encoder_to_decoder output), the position rows' column
+            # sum is d(mask_token) (each already summed over the clips that mask the position)
+            d_e2d = dx_full[:w.Me]
+            ops.colsum_bf16(dx_full[w.Me:], gmask)
+            ops.gemm(ops.GEMM_NN, ops.EPI_BF16, d_e2d, s.bview("encoder_to_decoder.weight"), w.d_encout)
+            self._wgrad(d_e2d, enc_out_bf16, s.g2d("encoder_to_decoder.weight"))
+            return w.d_encout
         handoff = self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") == "1"
         if self.side is not None and handoff and d.dec_dim % 8 == 0 and d.dec_dim <= 512 and os.environ.get("MOFO_ASM_DEFER", "1") == "1":
             # d(mask_token) is needed by nothing before the optimizer (or the bucket hand-over, which is issued on the side stream
@@ -920,7 +969,7 @@ class PretrainRuntime:
                     raise ValueError("this workspace's last decoder block keeps the masked tokens only: return_token_num must be their count")
                 x = self._block_fwd_last(W, L, x, w.B, w.N, d.dec_heads, w.N - n_ret)
             else:
-                x = self._block_fwd(W, L, x, w.B, w.N, d.dec_heads)
+                x = self._block_fwd(W, L, x, w.B, w.N, d.dec_heads, share=w.dec0 if i == 0 and getattr(w, "dec_share", False) else None)
         if compact:      # the last block's output holds exactly the rows decoder.norm / head read
             ops.layernorm_fwd(x, s.view(p + "norm.weight"), s.view(p + "norm.bias"), d.eps, w.dec_ln, w.dec_mean, w.dec_rstd)
         else:
@@ -955,8 +1004,15 @@ class PretrainRuntime:
                          s.gview(p + "norm.weight"), s.gview(p + "norm.bias"), rows_in=n_ret, rows_out=w.N, row_off=w.N - n_ret)
         for i in range(top, -1, -1):
             x_in = w.dec[i - 1].x_out if i > 0 else x_full.view(w.Md, d.dec_dim)
-            self._block_bwd(self.decW[i], w.dec[i], S, j, x_in, w.B, w.N, d.dec_heads, flush=(i == 0))
+            share = w.dec0 if i == 0 and getattr(w, "dec_share", False) else None
+            self._block_bwd(self.decW[i], w.dec[i], S, j, x_in, w.B, w.N, d.dec_heads, flush=(i == 0), share=share)
             j += 1
+        if getattr(w, "dec_share", False):
+            if not defer_ln:
+                self._ln_flush()
+                if self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+                    self._join_side(S)
+            return w.dec0.dxcat                  # gradient wrt the CAT rows of the decoder input, bf16 [B*n_vis + N, D]
         if S.pending:                      # a decoder without blocks: the head's weight gradient alone
             self._wgrad_flush(S, S.gidx % 2, w.N)
         if not defer_ln:                   # defer_ln: the caller runs the encoder backward next; its final LayerNorm reduce and its

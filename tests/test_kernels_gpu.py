@@ -455,6 +455,42 @@ def test_layernorm_bwd_partial_residual(dev, Bc, n_all, skip, D, xb):
         ops.layernorm_bwd(dy, x, w, mean, rstd, dres_c, None, dxb, dw, db, partial_ws=ws, dres_rows=(n_all + 1, skip))
 
 
+@pytest.mark.parametrize("B,N,n_vis,W", [(32, 1568, 160, 1152), (3, 288, 72, 384), (5, 64, 17, 128), (1, 40, 8, 8)])
+def test_dec0_gather_reduce_inverse(dev, B, N, n_vis, W):
+    """decoder block 0 row sharing (include/mofo_hip.h): gather = index_select of the cat rows, reduce = its adjoint with an f32
+    sum per position (clip order), inverse = the slot table; plus the adjoint identity <gather(c), f> == <c, reduce(f)> in f64"""
+    from mofo_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + N)
+    n_msk = N - n_vis
+    msk = torch.stack([torch.randperm(N, generator=g)[:n_msk].sort().values for _ in range(B)]).to(torch.int32).to(dev)
+    cat = _rand((B * n_vis + N, W), dev, 3)
+    full = torch.empty(B * N, W, dtype=BF16, device=dev)
+    ops.dec0_gather(cat, msk, N, full)
+    src = torch.cat([torch.arange(B * n_vis, device=dev).view(B, n_vis), B * n_vis + msk.long()], dim=1).reshape(-1)
+    assert torch.equal(full, cat[src])
+    inv = torch.empty(B, N, dtype=torch.int32, device=dev)
+    ops.dec0_inverse(msk, N, inv)
+    ref_inv = torch.full((B, N), -1, dtype=torch.int32, device=dev)
+    ref_inv.scatter_(1, msk.long(), torch.arange(n_msk, dtype=torch.int32, device=dev).expand(B, n_msk).contiguous())
+    assert torch.equal(inv, ref_inv)
+    f = _rand((B * N, W), dev, 4)
+    out = torch.full((B * n_vis + N, W), float("nan"), dtype=BF16, device=dev)
+    ops.dec0_reduce(f, inv, n_vis, out)
+    f3 = f.view(B, N, W)
+    assert torch.equal(out[:B * n_vis], f3[:, :n_vis].reshape(B * n_vis, W))
+    acc = torch.zeros(N, W, dtype=torch.float32, device=dev)
+    for b in range(B):                                  # clip order, f32, one rounding at the end: what the kernel does
+        acc.index_add_(0, msk[b].long(), f3[b, n_vis:].float())
+    assert torch.equal(out[B * n_vis:], acc.to(BF16))
+    lhs = (full.double() * f.double()).sum()
+    rhs = (cat.double() * torch.cat([out[:B * n_vis].double(), acc.double()])).sum()
+    assert float(lhs) == pytest.approx(float(rhs), rel=1e-9, abs=1e-6)
+    with pytest.raises(ValueError):
+        ops.dec0_gather(cat[:-1], msk, N, full)
+    with pytest.raises(ValueError):
+        ops.dec0_reduce(f, inv, n_vis + 1, out)
+
+
 def test_gemm_rejects_bad_shapes(dev):
     from mofo_amd import ops
     A = _rand((64, 96), dev, 1)

@@ -331,6 +331,64 @@ def test_last_decoder_block_on_masked_tokens_only(dev, monkeypatch, dec_depth, r
     assert float(got[0][1].double().norm()) == pytest.approx(ref_gn, rel=2e-2)
 
 
+@pytest.mark.parametrize("dec_depth,ratio", [(2, 0.75), (4, 0.9)])
+def test_first_decoder_block_shares_masked_rows(dev, monkeypatch, dec_depth, ratio):
+    """The first decoder block's rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262): by default LayerNorm
+    1, the qkv GEMM and their backward run once per position (ops.dec0_gather / dec0_reduce).  Two training steps against the same
+    model with MOFO_DEC0_SHARE=0 (every row computed, as the reference does): same forward to the bit where the GEMM route is the
+    same, same loss, every gradient tensor within bf16 summation noise; and against the oracle."""
+    from mofo_amd import optim_factory, utils
+    from mofo_amd.masking_generator import TubeMaskingGenerator
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(img_size=96, enc_dim=192, enc_depth=2, enc_heads=3, dec_dim=128, dec_depth=dec_depth, dec_heads=2)
+    B = 5
+    x = O.keyed_clips(B, cfg).to(dev)
+    np.random.seed(13)
+    gen = TubeMaskingGenerator(cfg.grid, ratio)
+    mask = torch.from_numpy(np.stack([gen() for _ in range(B)])).bool().to(dev)
+
+    def run(share):
+        monkeypatch.setenv("MOFO_DEC0_SHARE", "1" if share else "0")
+        model, P = _build(cfg, "xavier", dev)
+        P = dict(P)                                   # the reference's zero mask_token would hide half of what is shared here
+        P["mask_token"] = 0.5 * torch.randn(P["mask_token"].shape, generator=torch.Generator().manual_seed(3))
+        model.load_state_dict(P, strict=True)
+        opt = optim_factory.create_optimizer(_Args, model)
+        rt = model.runtime()
+        out = []
+        for _ in range(2):
+            loss = model.forward_loss(x, mask)
+            opt.zero_grad()
+            loss.backward()
+            w = next(iter(rt._ws.values()))
+            out.append((float(loss), rt.store.grads.clone(), w.pred.clone(), w.x_full.clone(), w.dec[0].qkv.clone()))
+            rt.grad_norm()
+            opt.step(norm_out=rt.norm_out)
+        model.check_status()
+        assert next(iter(rt._ws.values())).dec_share == share
+        return out, rt.store, P
+
+    ref, store, P = run(False)
+    got, _, _ = run(True)
+    assert torch.equal(got[0][3], ref[0][3])                        # the assembled decoder input: bit-identical
+    assert _rel(got[0][4], ref[0][4]) < 1e-3                          # block 0 qkv rows (same products; the GEMM route may differ with M)
+    for step, ((l0, g0, p0, _, _), (l1, g1, p1, _, _)) in enumerate(zip(ref, got)):
+        assert l1 == pytest.approx(l0, rel=2e-5 if step == 0 else 1e-3)
+        assert _rel(p1, p0) < (2e-3 if step == 0 else 1e-2)
+        tot = float(g0.double().norm())
+        for n in store.names:
+            o, k = store.offset[n], int(np.prod(store.shape[n]))
+            a, b = g0[o:o + k], g1[o:o + k]
+            assert float((a - b).double().norm()) <= (1e-2 if step == 0 else 3e-2) * max(float(a.double().norm()), 1e-3 * tot), n
+    ref_loss, ref_gn, ref_g = O.train_step(x.cpu(), mask.cpu(), P, cfg)
+    assert got[0][0] == pytest.approx(ref_loss, rel=1e-3)
+    assert float(got[0][1].double().norm()) == pytest.approx(ref_gn, rel=2e-2)
+    for n in ("mask_token", "encoder_to_decoder.weight", "decoder.blocks.0.norm1.weight", "decoder.blocks.0.norm1.bias",
+              "decoder.blocks.0.attn.qkv.weight", "decoder.blocks.0.attn.q_bias", "decoder.blocks.0.attn.v_bias"):
+        o, k = store.offset[n], int(np.prod(store.shape[n]))
+        assert _rel(got[0][1][o:o + k].cpu().view(-1), ref_g[n].reshape(-1)) < 3e-2, n
+
+
 @pytest.mark.parametrize("order", ["small_first", "large_first"])
 def test_split_and_unsplit_workspaces_share_one_gradient_buffer(dev, monkeypatch, order):
     """zero_grads() skips tensors that a recorded backward OVERWRITES (unsplit grouped weight gradients).  A second workspace of
