@@ -146,14 +146,6 @@ int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, in
                                 int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
 int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                  int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
-/* The ONE-pass form mofo_attention_bwd uses for N > 160 (5 MFMA products per (query tile, key tile) pair instead of the 7
- * of the dq + dkv passes): blocks own strips of key tiles, keep dK / dV in registers and ADD their strip's dQ tiles to the
- * q third of dqkv with packed-bf16 atomics -- that third must be ZERO on entry; mofo_attention_delta_zero_dq computes delta
- * and clears it in one launch.  dq is a sum of <= ceil(N/224) bf16-rounded partials: run-to-run differences in its last bit. */
-int mofo_attention_delta_zero_dq(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta,
-                                 void* dqkv, int lddqkv, void* stream);
-int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
-                               int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream);
 
 /* ---- RCCL communicator: the stand-alone route to the ONE collective of the path -- the per-step gradient
  * all-reduce of run_mae_pretraining.py:225-227 (DDP) over the group of utils.py:289-294 -- for callers that bind this library

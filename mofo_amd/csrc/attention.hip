@@ -27,25 +27,9 @@ __device__ unsigned long long g_attn_trace[1 << 18];
     do {                                                                                           \
         if (threadIdx.x == 0 && blockIdx.x < (1 << 15)) g_attn_trace[blockIdx.x * 8 + (slot)] = __builtin_readcyclecounter(); \
     } while (0)
-// one-pass backward: waves 0 and 4 (the two waves of one SIMD) of every block, query block 2, step 3
-// (values are kept in registers and stored once at the end of the kernel: a global store per stamp would sit in vmcnt
-// and make the build's barriers wait for the LDS-DMA in flight, which the real build never does)
-#define OP_STAMP(qb, st, slot)                                                                     \
-    do {                                                                                           \
-        if ((qb) == 2 && (st) == 3) op_stamp[slot] = __builtin_readcyclecounter();                 \
-    } while (0)
-#define OP_STAMP_DECL unsigned long long op_stamp[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define OP_STAMP_FLUSH()                                                                           \
-    do {                                                                                           \
-        if ((threadIdx.x & 255) == 0 && blockIdx.x < (1 << 14))                                    \
-            for (int i_ = 0; i_ < 8; ++i_) g_attn_trace[blockIdx.x * 16 + (threadIdx.x >> 8) * 8 + i_] = op_stamp[i_]; \
-    } while (0)
 #else
 #define ATTN_STAMP(kt, slot)
 #define FUSED_STAMP(slot)
-#define OP_STAMP(qb, st, slot)
-#define OP_STAMP_DECL
-#define OP_STAMP_FLUSH()
 #endif
 
 // raised priority while a wave issues its MFMA groups: the matrix pipe is fed first, other waves' VALU fills the issue gaps
@@ -371,9 +355,14 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 // over all 32 gaps needs the S / dP accumulators double-buffered across query tiles, which no longer fits 256 arch VGPRs.  Removed.
 // What the phase stamps (tools/attn_trace.py dkv) show: of ~2 440 cycles per tile and wave, 730 go to writing the next
 // tile to LDS, the barrier and issuing the next global loads; the two 8-MFMA groups take 610 and 850 cycles (256 each alone).
-// FOLD (1: delta, 2: delta and the exp2 argument): see attn_pingpong.h "Vector diet" -- the wave's V fragments are held negated and
-// dP starts at +delta (exact); with 2 the K fragments are held as bf16(-c K) and S starts at +lse2, p = exp2(-S).  The initial values
-// are read from the staged tile straight into the accumulator registers: 32 VALU per tile (fma, sub) and 32 operand registers go.
+// FOLD, the vector diet of this pass (1: delta, 2: delta and the exp2 argument; found while building the 8-wave ping-pong form of
+// this kernel -- removed in round 4 after its grid was priced, last in commit 5a7849c as csrc/attn_pingpong.h; profiles/r03_attn_dkv_ab.txt):
+//   * dP - delta: the wave's V fragments are held NEGATED and the dP accumulator starts at +delta (read from the staged tile straight
+//     into the accumulator registers): acc = delta - dO.V^T = -(dP - delta).  Exact; the sign is returned when dK is stored.
+//   * exp2(c S - lse2): the wave's K fragments are held as bf16(-c K) and the S accumulator starts at +lse2: acc = lse2 - c Q.K^T,
+//     p = exp2(-acc) (the negation is the instruction's source modifier).  Rounds c K instead of K to bf16: the same order as the
+//     bf16 rounding of P itself (profiles/r04_dkv_fold_drift.txt: no drift over 2 000 steps against FOLD 0).
+// 32 VALU per tile (fma, sub) and 32 operand registers go; left per 32 x 32 tile and lane: 16 v_exp, 16 v_mul, 16 pack conversions.
 template <int NW, bool WHOLE, bool U2 = false, int FOLD = 0>
 __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                             float scale, const bf16_t* __restrict__ dout, int lddo,
@@ -682,7 +671,6 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
 }
 
-#include "attn_pingpong.h"
 
 // ------------------------------------------------------------------------------------------------ short sequences: ONE backward kernel
 // N <= 160 (the encoder's visible tokens): delta, dQ, dK and dV of one (clip, head) in ONE block of 5 waves, Q / dO / K
@@ -879,277 +867,10 @@ __global__ __launch_bounds__(FUSED_NW * 64) void attn_bwd_fused_kernel(const bf1
     }
 }
 
-// ------------------------------------------------------------------------------------------------ long sequences: ONE backward pass
-// N > 160 (the decoder's 1568 tokens): the two-pass form (attn_q_kernel<.,1> for dQ + attn_dkv_kernel for dK/dV) executes
-// 7 MFMA products per (query tile, key tile) pair for the algorithmic 5 -- S and dP are computed twice.  Here every pair is
-// visited once, as in attn_bwd_fused_kernel: a block owns a STRIP of up to OP_T key tiles of one (clip, head) (wave j: key
-// tile j, its dK_j / dV_j in registers for the whole kernel) and sweeps all query tiles in blocks of OP_T.  Inside a query
-// block the OP_T x OP_T (key tile, query tile) pairs run as a Latin square: at step s wave j works on query slot
-// i = (j + s) mod OP_T and leaves dS_ij in its 2 KiB scratch as [key][query] bf16; after a barrier the wave that OWNS
-// query slot i picks it up through the transposing `ds_read_b64_tr_b16` and adds K_j^T dS_ij to its dQ_i^T registers, so
-// after OP_T steps dQ_i holds the sum over the whole strip.  Only that strip-level sum leaves the block: the strips of a
-// (clip, head) (7 at N = 1568) add their dQ tiles with `global_atomic_pk_add_bf16`, two 128-B row segments per
-// wave-instruction, into the q third of dqkv, which mofo_attention_delta has zeroed (2.5 x strip keys = 560 FLOP per atomic
-// byte: 270 MB of adds per layer, ~0.2 ms at the chip's atomic rate, hidden under ~0.35 ms of MFMA work; the f32 form
-// would need 540 MB and set the kernel's time).  bf16 accumulation over <= 14 strips costs ~2x the rounding error of one
-// final bf16 rounding (guide, "Global float atomics") -- inside the 2e-2 bound of the kernel test.
-// LDS: the query block's Q / dO tiles + (lse2, delta) rows double-buffered (the next block is loaded one tile per step),
-// the strip's K tiles, the scratch: OP_T x 23 040 B = 161 280 B for OP_T = 7 -> one block per CU, 7 waves.
-constexpr int OP_T = 7;
-constexpr int OP_QBUF = OP_T * (2 * TILE + 256);                      // one query block: Q tiles, dO tiles, [32 lse2 | 32 delta] rows
-constexpr int OP_SMEM = 2 * OP_QBUF + OP_T * TILE + OP_T * 32 * SCR;  // 161 280 B
-
-__global__ __launch_bounds__(OP_T * 64) void attn_bwd_onepass_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nstrips, int tps, int G, int N,
-                                                                        int H, float c, float scale, const bf16_t* __restrict__ dout, int lddo,
-                                                                        const float* __restrict__ lse2, const float* __restrict__ delta,
-                                                                        bf16_t* __restrict__ dqkv, int lddqkv) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char osm[];
-    unsigned char* QB = osm;                                   // [2][OP_QBUF]
-    // region offsets as OPAQUE scalars: folded into the per-lane fragment offsets they gave every region its own set of
-    // hoisted address VGPRs (spilled and reloaded inside the step loop -- and a reload's vmcnt(0) drains the LDS-DMA)
-    unsigned kt_off = 2 * OP_QBUF, sc_off = 2 * OP_QBUF + OP_T * TILE;
-    asm volatile("" : "+s"(kt_off), "+s"(sc_off));
-    unsigned char* KT = osm + kt_off;                          // [OP_T][TILE]
-    unsigned char* SC = osm + sc_off;                          // [OP_T][32 x SCR]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    int xb, b, h;
-    if (!decode_block(nstrips, G, H, xb, b, h)) return;
-    const int D = H * HD;
-    const bf16_t* base = qkv + (size_t)b * N * ldqkv;
-    const bf16_t* qp = base + h * HD;
-    const bf16_t* kp = base + D + h * HD;
-    const bf16_t* vp = base + 2 * D + h * HD;
-    const bf16_t* dop = dout + (size_t)b * N * lddo + h * HD;
-    const float* lp = lse2 + ((size_t)b * H + h) * N;
-    const float* dlp = delta + ((size_t)b * H + h) * N;
-    const int nkt = (N + 31) >> 5;                             // 32-row tiles along the sequence (keys and queries alike)
-    const int kt0 = xb * tps;
-    const int tk = min(tps, nkt - kt0);                        // key tiles of this strip (<= OP_T)
-    if (tk <= 0) return;
-    const int nqb = (nkt + OP_T - 1) / OP_T;                   // query blocks
-
-    // ---- this wave's key tile: V rows as MFMA B fragments (key on the lane); K rows go to LDS (S operand and dQ operand)
-    const bool has_key = wave < tk;
-    const int ki = (kt0 + wave) * 32 + (lane & 31);
-    const int krow = ki < N ? ki : N - 1;
-    const bool kvalid = has_key && ki < N;
-    bf16x8 vf[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
-    for (int idx = tid; idx < tk * 256; idx += OP_T * 64) {
-        const int t = idx >> 8, rl = (idx >> 3) & 31, ch = idx & 7;
-        int r = (kt0 + t) * 32 + rl;
-        r = r < N ? r : N - 1;
-        *(u32x4*)(KT + t * TILE + rl * RS + ((ch ^ swz(rl)) << 4)) = *(const u32x4*)(kp + (size_t)r * ldqkv + ch * 8);
-    }
-    // ---- first query block: all its tiles at once (8 x 16 B per thread in flight)
-    {
-        constexpr int PER = (OP_T * 512 + OP_T * 64 - 1) / (OP_T * 64);   // 16-B chunks of Q and dO per thread
-        u32x4 st[PER];
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = tid + k * OP_T * 64;
-            const int t = idx >> 9, which = (idx >> 8) & 1, rl = (idx >> 3) & 31, ch = idx & 7;
-            int r = t * 32 + rl;
-            r = r < N ? r : N - 1;
-            st[k] = u32x4{0u, 0u, 0u, 0u};
-            if (t < OP_T && t < nkt) st[k] = *(const u32x4*)((which ? dop + (size_t)r * lddo : qp + (size_t)r * ldqkv) + ch * 8);
-        }
-#pragma unroll
-        for (int k = 0; k < PER; ++k) {
-            const int idx = tid + k * OP_T * 64;
-            const int t = idx >> 9, which = (idx >> 8) & 1, rl = (idx >> 3) & 31, ch = idx & 7;
-            if (t < OP_T && t < nkt) *(u32x4*)(QB + t * TILE + which * (OP_T * TILE) + rl * RS + ((ch ^ swz(rl)) << 4)) = st[k];
-        }
-        float* LD = (float*)(QB + 2 * OP_T * TILE);
-        for (int idx = tid; idx < OP_T * 64; idx += OP_T * 64) {
-            const int t = idx >> 6, e = idx & 63, qq = t * 32 + (e & 31);
-            // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
-            LD[idx] = e < 32 ? (qq < N ? lp[qq] : 1.0e30f) : (qq < N ? dlp[qq] : 0.f);
-        }
-    }
-    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16(), q0 = zero16(), q1 = zero16();
-    __syncthreads();
-
-    unsigned char* Sw = SC + wave * (32 * SCR);
-    const unsigned char* Kw = KT + wave * TILE;
-    // ---- the three MFMA groups of a step.  Written as explicit load groups ahead of MFMA groups, pinned with sched_barrier:
-    // left to itself hipcc puts every fragment read directly in front of its MFMA (`ds_read; s_waitcnt lgkmcnt(0); v_mfma`
-    // x 20), and with two waves per SIMD nothing hides those LDS round trips.
-    bf16x8 pf0, pf1, sf0, sf1, t0, t1;                         // P, dS (packed B operands) and the scratch fragments of a step
-    bf16x8 ot00, ot10, ot01, ot11;                             // dO^T fragments (read under the score MFMAs, used by the dV MFMAs)
-    // S = Q K^T, dP = dO V^T (key on the lane), P = exp2(c S - lse2), dS = P (dP - delta); dS also goes to the scratch
-    auto pair_scores = [&](const unsigned char* Qt, const unsigned char* Ot, const float* Lt) {
-        const float* Dt = Lt + 32;
-        bf16x8 qa[4], ka[4], oa[4];
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            qa[ks] = row_frag(Qt, ks, lane);
-            ka[ks] = row_frag(Kw, ks, lane);
-            oa[ks] = row_frag(Ot, ks, lane);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        f32x16 s = zero16(), dpv = zero16();
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa[ks], ka[ks], s, 0, 0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(oa[ks], vf[ks], dpv, 0, 0, 0);
-        // dO^T fragments for dV: their LDS latency passes under the two MFMA chains and the exponentials
-        ot00 = tr_frag(Ot, 0, 0, lane), ot10 = tr_frag(Ot, 1, 0, lane), ot01 = tr_frag(Ot, 0, 1, lane), ot11 = tr_frag(Ot, 1, 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        float p[16], ds[16];
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
-            const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int r = 4 * rg + e;
-                const float pr = fast_exp2(s[r] * c - lv[e]);
-                p[r] = pr;
-                ds[r] = pr * (dpv[r] - dv[e]);
-            }
-        }
-        pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
-        sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
-        // dS tile to the scratch as [key = lane & 31][query]; a key beyond N must not reach dQ
-        const int kr = lane & 31;
-        const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
-        const u32x2 z = {0u, 0u};
-        const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
-                            kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
-    };
-    // dV_j^T += dO^T P, dK_j^T += Q^T dS
-    auto pair_dvdk = [&](const unsigned char* Qt) {
-        const bf16x8 qt00 = tr_frag(Qt, 0, 0, lane), qt10 = tr_frag(Qt, 1, 0, lane), qt01 = tr_frag(Qt, 0, 1, lane), qt11 = tr_frag(Qt, 1, 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot00, pf0, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot01, pf0, dv1, 0, 0, 0);
-        dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot10, pf1, dv0, 0, 0, 0);
-        dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot11, pf1, dv1, 0, 0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt00, sf0, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt01, sf0, dk1, 0, 0, 0);
-        dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt10, sf1, dk0, 0, 0, 0);
-        dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt11, sf1, dk1, 0, 0, 0);
-    };
-    // dQ_(slot wave)^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query]  (t0, t1: the scratch fragments of wave j)
-    auto slot_dq = [&](int j) {
-        const unsigned char* Kj = KT + j * TILE;
-        const bf16x8 k00 = tr_frag(Kj, 0, 0, lane), k10 = tr_frag(Kj, 1, 0, lane), k01 = tr_frag(Kj, 0, 1, lane), k11 = tr_frag(Kj, 1, 1, lane);
-        __builtin_amdgcn_sched_barrier(0);
-        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k00, t0, q0, 0, 0, 0);
-        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k01, t0, q1, 0, 0, 0);
-        q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k10, t1, q0, 0, 0, 0);
-        q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k11, t1, q1, 0, 0, 0);
-    };
-    // (Measured and dropped: a partner stagger -- waves 4.. issuing a step's dV / dK and dQ MFMA groups at the start of the next
-    // step so that they run beside the SIMD partner's exponentials -- 590 vs 563 us: a wave's own chain operand reads -> 8 MFMAs
-    // -> ~130 VALU -> 8 MFMAs -> barrier -> 4 reads -> barrier -> 4 MFMAs is ~2 000 clk of latency per step by itself, and 256
-    // VGPRs allow no third wave per SIMD to fill it.)
-    for (int qb = 0; qb < nqb; ++qb) {
-        const int cur = qb & 1;
-        const unsigned char* QT = QB + cur * OP_QBUF;
-        const unsigned char* OT = QT + OP_T * TILE;
-        const float* LD = (const float*)(QT + 2 * OP_T * TILE);
-        unsigned char* NQ = QB + (cur ^ 1) * OP_QBUF;          // the next query block is staged here, one tile per step
-        const int tq = min(OP_T, nkt - qb * OP_T);             // query tiles of this block
-        const int tqn = qb + 1 < nqb ? min(OP_T, nkt - (qb + 1) * OP_T) : 0;
-        for (int st = 0; st < OP_T; ++st) {
-            const bool last = st == OP_T - 1;
-            int jq = wave - st;
-            jq = jq < 0 ? jq + OP_T : jq;                      // the wave whose key tile met query slot `wave` in this step
-            const bool do_q = wave < tq && jq < tk;
-            int qs = wave + st;
-            qs = qs >= OP_T ? qs - OP_T : qs;                  // query slot this wave's key tile meets in this step
-            if (has_key && qs < tq) {
-                pair_scores(QT + qs * TILE, OT + qs * TILE, LD + qs * 64);
-                pair_dvdk(QT + qs * TILE);
-            }
-            __syncthreads();                                   // every wave's dS of this step is in its scratch
-            // ---- tile `st` of the next query block by LDS-DMA: waves 0..3 move 8-row pieces of Q and dO, wave 4 the (lse2, delta)
-            // row.  Issued behind the step's first barrier: in step 0 the buffer it writes is the one the slower waves may
-            // still be flushing their dQ tiles through.  (Issuing a step earlier -- two tiles in step 0, none in the last, so
-            // that the wait before the block's last barrier never sees a fresh piece -- measured 6 % SLOWER.)
-            if (st < tqn) {
-                const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-                const int qt_next = (qb + 1) * OP_T + st;
-                const unsigned nq_lds = (unsigned)(size_t)LDS_PTR(NQ);
-                if (wave_u < 4) {
-                    const int rl = wave_u * 8 + (lane >> 3);
-                    int r = qt_next * 32 + rl;
-                    r = r < N ? r : N - 1;
-                    const int ch = (lane & 7) ^ swz(rl);               // LDS position (lane & 7) of row rl holds source chunk ch
-                    dma_b128(qp + (size_t)r * ldqkv + ch * 8, nq_lds + st * TILE + wave_u * 1024);
-                    dma_b128(dop + (size_t)r * lddo + ch * 8, nq_lds + OP_T * TILE + st * TILE + wave_u * 1024);
-                } else if (wave_u == 4) {
-                    const int qq = qt_next * 32 + (lane & 31);
-                    const float* src = lane < 32 ? (qq < N ? lp + qq : g_pad_row) : (qq < N ? dlp + qq : g_pad_row + 1);
-                    dma_b32(src, nq_lds + 2 * OP_T * TILE + st * 256);
-                }
-            }
-            // The scratch is free as soon as its fragments sit in registers: the step's second barrier comes right behind
-            // those reads, and the dQ MFMAs (and the next step's operand reads) run past it.
-            if (do_q) {
-                const unsigned char* Sj = SC + jq * (32 * SCR);
-                t0 = tr_frag_scratch(Sj, 0, lane);
-                t1 = tr_frag_scratch(Sj, 1, lane);
-            }
-            if (last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces of the next block have landed
-            __syncthreads();                                   // the scratches are free again (last step: the next block is visible)
-            if (do_q) slot_dq(jq);
-        }
-        // ---- query slot `wave` has met every key tile of the strip: its dQ^T tile [64 d][32 queries] leaves the block.
-        // Transposed through the finished query block's (now idle) Q buffer into row-contiguous form: one atomic
-        // wave-instruction = two query rows x 128 B (the shape that runs at the full atomic rate); the next block's first
-        // staging write into this buffer comes after its first step's barrier, i.e. after every wave's flush reads.
-        if (wave < tq) {
-            // 136-B rows (no XOR): the read side then needs ONE lane address + immediate offsets.  (The first version's
-            // per-row swizzle gave 16 hoisted address VGPRs, spilled; each reload's vmcnt(0) waited for the previous atomic's
-            // round trip: the flush, not the MFMA work, set the kernel's time.)  8 KiB of the idle Q / dO tile area per wave.
-            constexpr int FR = 136;
-            unsigned char* F = QB + cur * OP_QBUF + wave * (2 * TILE);
-            const int qr = lane & 31;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const f32x16& a = dt ? q1 : q0;
-#pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const u32x2 o = {pack_bf16x2(a[4 * rg] * scale, a[4 * rg + 1] * scale), pack_bf16x2(a[4 * rg + 2] * scale, a[4 * rg + 3] * scale)};
-                    *(u32x2*)(F + qr * FR + 8 * (8 * dt + 2 * rg + hh)) = o;   // d = 32 dt + 8 rg + 4 hh .. + 3
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            const int q_base = (qb * OP_T + wave) * 32 + hh;             // this lane's first query row
-            const int dw = lane & 31;                                    // dword dw of a row = d 2 dw, 2 dw + 1
-            const unsigned char* fr = F + hh * FR + 4 * dw;
-            bf16_t* dst = dqkv + ((size_t)b * N + q_base) * lddqkv + h * HD + 2 * dw;
-            typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
-#pragma unroll
-            for (int it = 0; it < 16; ++it) {
-                const unsigned v = *(const unsigned*)(fr + it * 2 * FR);
-                if (q_base + 2 * it < N)
-                    __builtin_amdgcn_global_atomic_fadd_v2bf16((__attribute__((address_space(1))) bf16x2_t*)(dst + (size_t)it * 2 * lddqkv),
-                                                               __builtin_bit_cast(bf16x2_t, v));
-            }
-            q0 = zero16();
-            q1 = zero16();
-        }
-    }
-    if (!kvalid) return;
-    bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
-    store_T(drow + D, dk0, dk1, scale, hh);
-    store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
-}
-
 // delta[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]: 8 lanes per (token, head), 16-B loads, 3-step shuffle reduce.
-// Its own kernel so that the dQ pass and the dK/dV pass (which both need it) can run concurrently on two streams.
-// `zero_q` (the q third of dqkv, row stride ldz) is cleared on the way for the one-pass backward, whose strips ADD their dQ tiles.
+// Its own kernel: the dQ pass and the dK/dV pass both need it.
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ out, int ldo, const bf16_t* __restrict__ dout,
-                                                         int lddo, int N, int H, long long pairs, float* __restrict__ delta,
-                                                         bf16_t* __restrict__ zero_q, int ldz, int qb) {
+                                                         int lddo, int N, int H, long long pairs, float* __restrict__ delta, int qb) {
     // qb: `out` / `dout` hold the query rows qb .. N - 1 of every clip compactly (tok counts those rows); delta keeps whole-sequence indices
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long pr = i >> 3;
@@ -1162,10 +883,6 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
         const bf16x8 o = *(const bf16x8*)(out + tok * ldo + h * HD + ch * 8);
 #pragma unroll
         for (int j = 0; j < 8; ++j) part += (float)a[j] * (float)o[j];
-        if (zero_q) {
-            const long long bz = tok / (N - qb);
-            *(u32x4*)(zero_q + (bz * N + qb + (tok - bz * (N - qb))) * ldz + h * HD + ch * 8) = u32x4{0u, 0u, 0u, 0u};
-        }
     }
     part += __shfl_xor(part, 1, 64);
     part += __shfl_xor(part, 2, 64);
@@ -1257,55 +974,25 @@ static int bwd_check(const char* who, const void* qkv, int ldqkv, const void* do
     return MOFO_OK;
 }
 
-static int launch_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* zero_q, int ldz, void* stream,
-                        int q_begin = 0) {
+static int launch_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* stream, int q_begin = 0) {
     if (!out || !dout || !delta) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: null pointer");
-    if (B <= 0 || N <= 0 || H <= 0 || ldo % 8 || lddo % 8 || (zero_q && ldz % 8)) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: bad sizes");
+    if (B <= 0 || N <= 0 || H <= 0 || ldo % 8 || lddo % 8) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta: bad sizes");
     int rc = check_range("mofo_attention_delta", N, q_begin);
     if (rc) return rc;
     const long long pairs = (long long)B * (N - q_begin) * H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)out, ldo,
-                       (const bf16_t*)dout, lddo, N, H, pairs, delta, (bf16_t*)zero_q, ldz, q_begin);
+                       (const bf16_t*)dout, lddo, N, H, pairs, delta, q_begin);
     MOFO_CHECK_LAUNCH("mofo_attention_delta");
     return MOFO_OK;
 }
 
 extern "C" int mofo_attention_delta(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta, void* stream) {
-    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, nullptr, 0, stream);
+    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, stream);
 }
 
 extern "C" int mofo_attention_delta_range(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, int q_begin, float* delta,
                                           void* stream) {
-    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, nullptr, 0, stream, q_begin);
-}
-
-// delta AND the cleared q third of dqkv: what mofo_attention_bwd_onepass expects to find
-extern "C" int mofo_attention_delta_zero_dq(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, float* delta,
-                                            void* dqkv, int lddqkv, void* stream) {
-    if (!dqkv || lddqkv < 3 * H * 64) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_delta_zero_dq: bad dqkv");
-    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, dqkv, lddqkv, stream);
-}
-
-// One-pass backward (N > 160; see attn_bwd_onepass_kernel).  The q third of dqkv must be ZERO on entry (the strips add to
-// it): mofo_attention_delta_zero_dq does both preparations in one launch.  The k and v thirds are overwritten.
-extern "C" int mofo_attention_bwd_onepass(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
-                                          int B, int N, int H, float scale, void* dqkv, int lddqkv, void* stream) {
-    int rc = bwd_check("mofo_attention_bwd_onepass", qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, dqkv, lddqkv);
-    if (rc) return rc;
-    if (ldqkv % 8 || lddqkv % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_bwd_onepass: leading dims must be multiples of 8");
-    static bool attr_set = false;
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void*)attn_bwd_onepass_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, OP_SMEM) != hipSuccess)
-            MOFO_FAIL(MOFO_ERUNTIME, "mofo_attention_bwd_onepass: cannot reserve %d bytes of LDS", OP_SMEM);
-        attr_set = true;
-    }
-    const int nkt = (N + 31) / 32;
-    const int nstrips = ceil_div(nkt, OP_T), tps = ceil_div(nkt, nstrips);
-    const float c = scale * 1.4426950408889634f;
-    hipLaunchKernelGGL(attn_bwd_onepass_kernel, dim3(8 * ceil_div(B * H, 8) * nstrips), dim3(OP_T * 64), OP_SMEM, (hipStream_t)stream,
-                       (const bf16_t*)qkv, ldqkv, nstrips, tps, B * H, N, H, c, scale, (const bf16_t*)dout, lddo, lse2, delta, (bf16_t*)dqkv, lddqkv);
-    MOFO_CHECK_LAUNCH("mofo_attention_bwd_onepass");
-    return MOFO_OK;
+    return launch_delta(out, ldo, dout, lddo, B, N, H, delta, stream, q_begin);
 }
 
 extern "C" int mofo_attention_bwd_dq(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2_in, const float* delta_in,
@@ -1344,33 +1031,6 @@ extern "C" int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const vo
     if ((rc = check_range("mofo_attention_bwd_dkv", N, q_begin))) return rc;
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
-    {
-        // ping-pong form (attn_pingpong.h): one block of NW = 5..8 waves per CU, the two waves of a SIMD one section apart.
-        // MOFO_ATTN_DKV_PP = 0: off, 1: on, 2: on with the exp2 argument folded into the K fragments / S accumulator (read per call).
-        const char* e = getenv("MOFO_ATTN_DKV_PP");
-        const int mode = e ? atoi(e) : 0;
-        if (mode > 0 && N > 160 && q_begin == 0) {
-            const int T = ceil_div(N, 32);
-            int nw = 8, best = 1 << 30;
-            for (int w = 8; w >= 5; --w) {
-                const int pad = ceil_div(T, w) * w - T;
-                if (pad < best) best = pad, nw = w;
-            }
-            const int nxb = ceil_div(T, nw);
-            const dim3 grid(8 * ceil_div(B * H, 8) * nxb);
-#define LAUNCH_PP(NW, F) hipLaunchKernelGGL((attn_dkv_pp_kernel<NW, F>), grid, dim3(NW * 64), 0, s, (const bf16_t*)qkv, ldqkv, nxb, B * H, N, H, c, scale, \
-                                            (const bf16_t*)dout, lddo, (const float*)lse2, (const float*)delta, (bf16_t*)dqkv, lddqkv)
-#define LAUNCH_PPF(NW) do { if (mode >= 2) LAUNCH_PP(NW, true); else LAUNCH_PP(NW, false); } while (0)
-            switch (nw) {
-                case 8: LAUNCH_PPF(8); break;
-                case 7: LAUNCH_PPF(7); break;
-                case 6: LAUNCH_PPF(6); break;
-                default: LAUNCH_PPF(5); break;
-            }
-            MOFO_CHECK_LAUNCH("mofo_attention_bwd_dkv(pp)");
-            return MOFO_OK;
-        }
-    }
     const char* ef = getenv("MOFO_ATTN_DKV_FOLD");      // read per call (A/B in one process): 0 = off, 1 = delta, 2 = delta + exp2 argument
     const int fold = ef ? atoi(ef) : 2;                 // same-process A/B at the decoder shape: 254.3 / 246.0 / 237.1 us (profiles/r03_attn_dkv_ab.txt)
 #define LAUNCH_KV(NW) do { if (N <= 160) { LAUNCH_KV_(NW, true, false, 0); } else if (fold >= 2) { LAUNCH_KV_(NW, false, true, 2); } \
@@ -1408,19 +1068,6 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
                            (bf16_t*)dqkv, lddqkv);
         MOFO_CHECK_LAUNCH("mofo_attention_bwd(fused)");
         return MOFO_OK;
-    }
-    // MOFO_ATTN_BWD_ONE_PASS=1: the one-pass form (5 MFMA products instead of 7, dQ by packed-bf16 atomics).  Measured at
-    // par with the two passes below (540 vs 567 + 19 us per ViT-B decoder layer alone, identical step time), so the default
-    // stays the deterministic, atomic-free two-pass form.
-    static int one_pass = -1;
-    if (one_pass < 0) {
-        const char* e = getenv("MOFO_ATTN_BWD_ONE_PASS");
-        one_pass = e ? atoi(e) : 0;
-    }
-    if (one_pass && lddqkv % 8 == 0 && ldqkv % 8 == 0) {
-        rc = mofo_attention_delta_zero_dq(out, ldo, dout, lddo, B, N, H, delta, dqkv, lddqkv, stream);
-        if (rc) return rc;
-        return mofo_attention_bwd_onepass(qkv, ldqkv, dout, lddo, lse2, delta, B, N, H, scale, dqkv, lddqkv, stream);
     }
     rc = mofo_attention_delta(out, ldo, dout, lddo, B, N, H, delta, stream);
     if (rc) return rc;

@@ -436,22 +436,6 @@ def attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
          B, N, H, scale, q_begin, _p(dqkv), _ld(dqkv))
 
 
-def attention_delta_zero_dq(out, dout, B, N, H, delta, dqkv):
-    """delta = rowsum(dO * O) and the q third of dqkv cleared, in one launch (what attention_bwd_onepass needs)"""
-    _chk(out, BF16, "out", 2), _chk(dout, BF16, "dout", 2), _chk(delta, F32, "delta"), _chk(dqkv, BF16, "dqkv", 2)
-    if out.shape != (B * N, H * 64) or dout.shape != out.shape or delta.numel() != B * H * N or dqkv.shape != (B * N, 3 * H * 64):
-        raise ValueError("attention_delta_zero_dq: shape mismatch")
-    _run("mofo_attention_delta_zero_dq", ("attn_delta",), 6.0 * out.numel(), _p(out), _ld(out), _p(dout), _ld(dout), B, N, H, _p(delta),
-         _p(dqkv), _ld(dqkv))
-
-
-def attention_bwd_onepass(qkv, dout, lse2, delta, B, N, H, scale, dqkv):
-    """dq (added to the zeroed q third), dk, dv in one pass over the (query tile, key tile) pairs: 10 B H N^2 64 FLOP"""
-    _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta)
-    _run("mofo_attention_bwd_onepass", ("attn_bwd_1p",), 10.0 * B * H * N * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),
-         B, N, H, scale, _p(dqkv), _ld(dqkv))
-
-
 def mask_to_indices(mask_u8, n_vis, vis_idx, msk_idx, status):
     _chk(mask_u8, U8, "mask", 2), _chk(vis_idx, I32, "vis_idx", 2), _chk(msk_idx, I32, "msk_idx", 2), _chk(status, I32, "status")
     B, N = mask_u8.shape

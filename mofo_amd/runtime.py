@@ -689,12 +689,6 @@ class PretrainRuntime:
             if n <= 160:
                 # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
                 ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
-            elif os.environ.get("MOFO_ATTN_BWD_ONE_PASS", "0") == "1":
-                # long sequences (the decoder): delta + cleared dq third, then ONE pass over the (query tile, key tile) pairs
-                # (5 MFMA products instead of 7; dQ strips meet through packed-bf16 atomics).  At par with the two passes in
-                # the step, so it is opt-in: the default stays atomic-free and deterministic.
-                ops.attention_delta_zero_dq(L.ao, S.dao, B, n, H, S.delta, T.dqkv)
-                ops.attention_bwd_onepass(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
             else:
                 ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
                 ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)

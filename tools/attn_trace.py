@@ -4,7 +4,7 @@
 Build first, in the container:  python tools/attn_trace.py --build   (attention.hip with -DMOFO_ATTN_TRACE)
 Stamps (wave 0 of every block, key tile 10): 0 tile start | 1 S = K Q^T MFMAs issued | 2 softmax / dS VALU done (operands
 packed) | 3 PV (or dQ) MFMAs issued | 4 next tile written to LDS | 5 barrier passed | 6 next-next tile's global loads issued.
-usage: attn_trace.py <fwd|dq|dkv|fused|onepass> B N H
+usage: attn_trace.py <fwd|dq|dkv|fused> B N H
 """
 import os, sys, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -36,17 +36,13 @@ ops.attention_delta(out, dout, B, N, H, delta)
 f = {"fwd": lambda: ops.attention_fwd(qkv, B, N, H, 0.125, out, lse),
      "dq": lambda: ops.attention_bwd_dq(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
      "dkv": lambda: ops.attention_bwd_dkv(qkv, dout, lse, delta, B, N, H, 0.125, dqkv),
-     "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta),
-     "onepass": lambda: ops.attention_bwd_onepass(qkv, dout, lse, delta, B, N, H, 0.125, dqkv)}[kind]
+     "fused": lambda: ops.attention_bwd(qkv, out, dout, lse, B, N, H, 0.125, dqkv, delta)}[kind]
 names = ["issue S MFMAs (4)", "softmax / dS VALU (+ dP MFMAs in dq)", "issue PV / dQ MFMAs (4)", "write next tile to LDS", "barrier", "issue next global loads"]
 if kind == "dkv":     # MOFO_ATTN_DKV_PIPE=0: the two-phase dK/dV kernel (query tile 10 of wave 0)
     names = ["row-fragment reads + S, dP MFMAs issued (8)", "tr-fragment reads issued + exp2 / dS VALU + packs", "dV, dK MFMAs issued (8)",
              "write next tile to LDS", "barrier", "issue next global loads"]
 if kind == "fused":   # N <= 160: the one-kernel backward
     names = ["issue loads + stage tiles + delta", "barrier", "step 0: pair (S, dP, dS, dV, dK)", "barrier", "step 0: dQ += K^T dS, barrier", "steps 1..T-1"]
-if kind == "onepass":   # N > 160: waves 0 and 4 (one SIMD's pair) of every block, query block 2, step 3
-    names = ["operand reads + S, dP MFMAs issued (8)", "exp / dS VALU, packs, scratch write, tr reads", "dV, dK MFMAs issued (8)",
-             "barrier 1 (every wave's dS written)", "scratch reads + barrier 2", "K^T reads + dQ MFMAs issued (4)"]
 for _ in range(5): f()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -62,14 +58,6 @@ buf = np.zeros((1 << 15) * 8, dtype=np.uint64)
 lib.mofo_debug_attn_trace_read.argtypes = [C.c_void_p, C.c_size_t]; lib.mofo_debug_attn_trace_read.restype = C.c_int
 assert lib.mofo_debug_attn_trace_read(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(-1, 8)
-if kind == "onepass":
-    both = buf.reshape(-1, 16)
-    both = both[both[:, 0] > 0].astype(np.int64)
-    for nm, o in (("wave 0", 0), ("wave 4", 8)):
-        dd = np.diff(both[:, o:o + 7], axis=1)
-        print(f"  {nm} phase medians: " + " ".join(f"{np.median(dd[:, i]):6.0f}" for i in range(6)))
-    print(f"wave 4 starts its step {np.median(both[:, 8] - both[:, 0]):.0f} clk after wave 0 (median); step length wave 0 "
-          f"{np.median(both[:, 6] - both[:, 0]):.0f}, wave 4 {np.median(both[:, 14] - both[:, 8]):.0f} clk")
 t = t[t[:, 0] > 0][:, :7].astype(np.int64)
 d = np.diff(t, axis=1)
 print(f"{len(t)} blocks")

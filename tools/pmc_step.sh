@@ -30,7 +30,7 @@ for k, d in agg.items():
 classes = {"gemm_tn_wgrad_f32": r"^gemm\w*_kernel<1, 1, 5", "gemm_nn_bf16": r"^gemm\w*_kernel<0, 1, 0", "gemm_nn_dgelu": r"^gemm\w*_kernel<0, 1, 4",
            "gemm_nt_bf16": r"^gemm\w*_kernel<0, 0, 0", "gemm_nt_bias_gelu": r"^gemm\w*_kernel<0, 0, 1", "gemm_nt_resid_f32": r"^gemm\w*_kernel<0, 0, 2",
            "gemm_nt_resid_bf16": r"^gemm\w*_kernel<0, 0, 6", "attn_fwd": r"^attn_q_kernel<\d, 0", "attn_bwd_dq": r"^attn_q_kernel<\d, 1",
-           "attn_bwd_dkv": r"^attn_dkv_kernel", "attn_bwd": r"^attn_bwd_fused_kernel", "attn_bwd_1p": r"^attn_bwd_onepass_kernel",
+           "attn_bwd_dkv": r"^attn_dkv_kernel", "attn_bwd": r"^attn_bwd_fused_kernel",
            "ln_fwd": r"^ln_fwd_kernel", "ln_bwd": r"^ln_bwd_kernel", "adamw": r"^adamw_kernel", "target_mse": r"^target_mse_kernel"}
 cls = {}
 for name, rx in classes.items():
