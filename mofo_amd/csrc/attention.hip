@@ -177,6 +177,12 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         L2 = lse2[((size_t)b * H + h) * N + qrow];
         dl = delta[((size_t)b * H + h) * N + qrow];     // rowsum(dO * O), from attn_delta_kernel
     }
+    // dQ pass: the dP accumulator STARTS at -delta (a lane holds 16 keys of ONE query, so the tuple is 16 copies of the lane's
+    // value, kept for the whole kernel: 16 registers for 16 subtractions per tile; exact up to the order of f32 additions;
+    // 194.4 -> 186.4 us at the decoder shape, same process: profiles/r04_attn_dq_fold.txt)
+    f32x16 ndl;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ndl[i] = -dl;
 
     f32x16 o0 = zero16(), o1 = zero16();
     float m = NEG_BIG, l = 0.f;
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 1, lane), pf1, o1, 0, 0, 0);
             ATTN_PRIO(0);
         } else {
-            f32x16 dp = zero16();
+            f32x16 dp = ndl;
             ATTN_PRIO(1);
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Vt, ks, lane), dof[ks], dp, 0, 0, 0);
@@ -289,7 +295,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
                 if constexpr (MASKED) {
                     if (kt * 32 + acc_row(r, hh) >= N) pr = 0.f;
                 }
-                p[r] = pr * (dp[r] - dl);
+                p[r] = pr * dp[r];
             }
             const bf16x8 f0 = pack_frag(p, 0), f1 = pack_frag(p, 1);
             ATTN_STAMP(kt, 2);

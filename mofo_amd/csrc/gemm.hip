@@ -170,7 +170,10 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
     // m % rows_in (the output itself is dense): the last decoder block runs on the masked tokens only, its residual input is the
     // whole-sequence stream of the block before.  rows_in >= 256 (every real shape): one division per wave tile, which then crosses at
     // most one group boundary; smaller groups (test geometries) divide per row.
-    constexpr bool RESID_MAP = (EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_RESID_BF16);
+    // Built for wave tiles of <= 64 rows only (the 128 x 128 / 64 x 128 forms and gemm_k2): in the 128-row wave tiles of the MI 8 and
+    // 256 x 256 kernels the mapped addressing pushed the residual prefetch chunks to scratch (784 B: ViT-L's proj / fc2 forward on
+    // gemm8 fell to 0.40 / 0.61 x) -- mofo_gemm_grouped never routes a problem with a row map there.
+    constexpr bool RESID_MAP = (EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_RESID_BF16) && WROWS <= 64;
     const bool rmap = RESID_MAP && p.rows_in > 0;
     const int rm_seg0 = rmap ? mb / p.rows_in : 0;
     const int rm_rem0 = rmap ? mb - rm_seg0 * p.rows_in : 0;
@@ -1183,11 +1186,16 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
             if (mi8 == 1 || eff8 > 1.25 * eff4) mi = 8;
         }
     }
+    // a residual row map (RESID_F32 / RESID_BF16 with rows_in > 0) exists in the epilogues of the <= 64-row wave tiles only
+    bool row_mapped = false;
+    for (int i = 0; i < count; ++i)
+        if ((a[i].epilogue == MOFO_EPI_RESID_F32 || a[i].epilogue == MOFO_EPI_RESID_BF16) && a[i].rows_in > 0) row_mapped = true;
+    if (row_mapped && mi == 8) mi = 4;
     // 256 x 256 counted-vmcnt kernel (gemm8.h).  MOFO_GEMM8 = 0: never, 1: wherever it is built and legal, unset: by shape.
     {
         const char* e = getenv("MOFO_GEMM8");    // read per call: A/B switches inside one process (tools/gemm8_ab.py)
         const int mode = e ? atoi(e) : -1;
-        bool legal = mode != 0 && gemm8_has(a[0].op, a[0].epilogue);
+        bool legal = mode != 0 && !row_mapped && gemm8_has(a[0].op, a[0].epilogue);
         for (int i = 0; legal && i < count; ++i) {
             // NT / NN stream whole K-tile PAIRS of a k-contiguous operand: a K-tile past the end would read the next row, not zeros
             if (a[i].op != MOFO_GEMM_TN && (a[i].K % 128 || a[i].splits > 1)) legal = false;

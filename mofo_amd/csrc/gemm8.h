@@ -84,18 +84,22 @@ __device__ __forceinline__ void g8_stage_half(__amdgpu_buffer_rsrc_t r, int v, i
         asm volatile("" ::: "memory");                                                     \
     } while (0)
 
-// A LOWER bound on the stores a wave issues in the epilogue of one FULL 128 x 64 wave tile (the vmcnt budget of the first K-tile
-// after it: `vmcnt(8 + S)` retires the prefetched loads that sit BEHIND the epilogue's S stores in the in-order counter only if
-// the wave really issued >= S stores -- a larger S waits for LESS, so S must never exceed the true count; a smaller S only
-// over-waits).  Ragged tiles take the bounds-checked epilogue path, whose row groups may be branched around: the caller falls
-// back to S = 0 after them.
+// A LOWER bound on the vector-memory operations (loads AND stores: one in-order counter) a wave issues in the epilogue of one FULL
+// 128 x 64 wave tile -- the vmcnt budget of the first K-tile after it: `vmcnt(8 + S)` retires the prefetched pieces that sit BEHIND
+// the epilogue's S operations in the counter only if the wave really issued >= S of them.  A larger S waits for LESS, so S must never
+// exceed the true count; a smaller S over-waits -- and what it then waits for are the epilogue's own first STORES, an HBM round trip
+// (the f32-residual epilogue interleaves its 32 residual loads with its 32 stores in chunks of 8: with S = 32 the wait would cover
+// its first 8 stores).
+// Counts per epilogue of gemm.hip, FULL path (no row group is branched around there; every load below is a separate dwordx4 / dwordx2):
+//   BF16 16 stores | BIAS_GELU 16 + 16 stores | DGELU_BF16, RESID_BF16 16 aux loads + 16 stores | F32 32 stores (the accumulating
+//   form: 128 atomics) | RESID_F32 32 residual loads + 32 stores | POS_F32 / POS_BF16 32 position-row loads + 32 stores (+ index loads).
+// Ragged tiles take the bounds-checked path, whose row groups may be branched around: the caller falls back to S = 0 after them.
 template <int EPI>
 constexpr int g8_epi_stores() {
-    return EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16 ? 16
-         : EPI == MOFO_EPI_BIAS_GELU ? 32
-         : EPI == MOFO_EPI_POS_BF16 ? 32
-         : EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_POS_F32 ? 32
-         : 32;   // F32: 32 plain 4-row stores; the accumulating form issues one atomic per row (128 >= 32)
+    return EPI == MOFO_EPI_BF16 ? 16
+         : EPI == MOFO_EPI_BIAS_GELU || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16 ? 32
+         : EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_POS_F32 || EPI == MOFO_EPI_POS_BF16 ? 64
+         : 32;   // F32
 }
 
 #ifdef MOFO_GEMM_TRACE
