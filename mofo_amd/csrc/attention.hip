@@ -134,6 +134,12 @@ __device__ __forceinline__ void dma_b32(const void* gsrc, unsigned lds_dst) {
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
 }
+// the same with a UNIFORM base address in an SGPR pair and a 32-bit per-lane byte offset: no 64-bit vector address arithmetic per piece
+__device__ __forceinline__ void dma_b128_s(const void* sbase, int voff, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
 __device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a query row beyond N: p = exp2(-big) = 0, delta = 0
 
 // ------------------------------------------------------------------------------------------------ forward
@@ -688,9 +694,12 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
 // i = (j + s) mod T and leaves dS_ij in its 2 KiB scratch as [key][query] bf16; after a barrier wave i picks up the
 // scratch of wave j = (i - s) mod T through the transposing `ds_read_b64_tr_b16` and adds K_j^T dS_ij to its dQ_i^T
 // registers; a second barrier frees the scratch.  delta = rowsum(dO * O) is computed while the tiles are staged.
-constexpr int FUSED_NW = 5;
+constexpr int FUSED_NW = 5;                                    // computing waves: one per 32-key / 32-query tile
+constexpr int FUSED_NT = FUSED_NW + 1;                         // + one LOADER wave: issues the next item's LDS-DMA, joins the barriers
 constexpr int SCR = 64;                                        // scratch row stride: 32 queries x bf16
-constexpr int FUSED_SMEM = 3 * FUSED_NW * TILE + FUSED_NW * 256 + FUSED_NW * 32 * SCR;   // 72 960 B
+constexpr int FUSED_SET = 3 * FUSED_NW * TILE;                 // Q, dO, K tiles of one (clip, head): 61 440 B
+constexpr int FUSED_LSE = 192;                                 // floats: 5 x 32 lse2 values in pieces of 64
+constexpr int FUSED_SMEM = 2 * FUSED_SET + FUSED_NW * TILE + FUSED_LSE * 4 + FUSED_NW * 256 + FUSED_NW * 32 * SCR;   // 155 648 B
 
 // B operand = TRANSPOSE of a wave's dS scratch [32 keys][32 queries]: lane <-> query, k slots <-> keys in tr_frag's order
 __device__ __forceinline__ bf16x8 tr_frag_scratch(const unsigned char* tile, int s2, int lane) {
@@ -706,171 +715,302 @@ __device__ __forceinline__ bf16x8 tr_frag_scratch(const unsigned char* tile, int
     return __builtin_bit_cast(bf16x8, r);
 }
 
-__global__ __launch_bounds__(FUSED_NW * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int G, int N, int H, float c,
+// accumulator tile pair D[d][row] (row on the lane) -> a wave-private [32 rows][64 d] bf16 LDS tile, 16-B chunk c of row r at c ^ (r & 7)
+__device__ __forceinline__ void stage_T(unsigned char* tile, const f32x16& a0, const f32x16& a1, float mul, int lane) {
+    const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) {
+        const f32x16& a = dt ? a1 : a0;
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const u32x2 o = {pack_bf16x2(a[4 * rg] * mul, a[4 * rg + 1] * mul), pack_bf16x2(a[4 * rg + 2] * mul, a[4 * rg + 3] * mul)};
+            *(u32x2*)(tile + r * RS + (((4 * dt + rg) ^ (r & 7)) << 4) + 8 * hh) = o;
+        }
+    }
+}
+// ... and from there to global rows dst[row][64] (row stride ld elements): 8 rows x 128 B per wave-instruction
+__device__ __forceinline__ void store_rows(bf16_t* dst, int ld, const unsigned char* tile, int rows, int lane) {
+    const int ch = lane & 7;
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int r = 8 * gq + (lane >> 3);
+        const u32x4 v = *(const u32x4*)(tile + r * RS + ((ch ^ (r & 7)) << 4));
+        if (r < rows) *(u32x4*)(dst + (size_t)r * ld + ch * 8) = v;
+    }
+}
+
+// PERSISTENT over the (clip, head) items (round 4): the block takes items blockIdx.x, blockIdx.x + gridDim.x, ... (the launcher caps the
+// grid at the CU count: at ~230 VGPRs one block fits a CU).  The phase stamps of the one-item-per-block form (tools/attn_trace.py fused
+// 32 160 12) read 11.2 k cycles of staging -- every block of a round pulls its 100 KB at the same moment, an HBM burst nothing overlaps
+// -- for 15.3 k of steps, and the 384 items of B = 32 made TWO such rounds on 256 CUs (36 us).  Now EVERYTHING the next item needs from
+// memory flies under the current item's steps by LDS-DMA: its Q / dO / K tiles into the other operand set, its O tiles and lse2 row into
+// a buffer of their own (delta = rowsum(dO * O) is then computed from LDS).  What the stamps taught on the way (each a built version):
+//   * the one register-path load, the wave's V fragments, is issued at the end of the current item BEFORE its result stores: gfx9 counts
+//     loads and stores in one in-order counter, and a load behind the stores waits for their HBM acknowledges (second item: 38 k cycles);
+//   * the results leave through LDS as whole 128-B rows (stage_T / store_rows): 48 scattered 8-B-per-row store instructions per wave
+//     took ~8 k cycles to issue, which a block that exits never noticed and a persistent block pays before its next item;
+//   * a wave keeps only about two LDS-DMA pieces of cold rows in flight: the 83 pieces of an item issued back to back block the issuing
+//     wave (all in step 0: +6 k cycles; a dedicated loader wave alone: 23-26 k, with ~8 instead of ~35 instructions per piece just the
+//     same) -- so every wave, the sixth "loader" wave included, issues ONE piece per sub-phase (three per step);
+//   * the lane-dependent parts of a piece's address are five registers computed once (uniform base in SGPRs + 32-bit lane offset).
+// Result: 36.0 -> 32.6 us per layer at B = 32, H = 12 (two-item blocks 66 k cycles: cold item 38 k incl. ~6 k of DMA issue, second item
+// 26 k; the floor is the 1 : 2 imbalance of 384 items on 256 CUs).  G <= CU count runs exactly one item per block as before.
+__global__ __launch_bounds__(FUSED_NT * 64) void attn_bwd_fused_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int G, int N, int H, float c,
                                                                           float scale, const bf16_t* __restrict__ out, int ldo,
                                                                           const bf16_t* __restrict__ dout, int lddo,
                                                                           const float* __restrict__ lse2, float* __restrict__ delta_out,
                                                                           bf16_t* __restrict__ dqkv, int lddqkv) {
     extern __shared__ __attribute__((aligned(16))) unsigned char fsm[];
-    unsigned char* QT = fsm;                                   // [5][TILE]
-    unsigned char* OT = QT + FUSED_NW * TILE;                  // dO tiles
-    unsigned char* KT = OT + FUSED_NW * TILE;
-    float* LD = (float*)(KT + FUSED_NW * TILE);                // [5][64]: 32 lse2 + 32 delta per query tile
+    unsigned char* OB = fsm + 2 * FUSED_SET;                   // [5][TILE] O tiles of the item being started
+    float* LSE = (float*)(OB + FUSED_NW * TILE);               // [5 x 32 + pad] its lse2 row
+    float* LD = LSE + FUSED_LSE;                               // [5][64]: 32 lse2 + 32 delta per query tile, as the steps read them
     unsigned char* SC = (unsigned char*)(LD + FUSED_NW * 64);  // [5][32 x SCR] per-wave dS scratch, [key][query]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    int xb, b, h;
-    if (!decode_block(1, G, H, xb, b, h)) return;
     const int D = H * HD;
-    const bf16_t* base = qkv + (size_t)b * N * ldqkv;
-    const bf16_t* qp = base + h * HD;
-    const bf16_t* kp = base + D + h * HD;
-    const bf16_t* vp = base + 2 * D + h * HD;
-    const bf16_t* dop = dout + (size_t)b * N * lddo + h * HD;
-    const bf16_t* op = out + (size_t)b * N * ldo + h * HD;
-    const float* lp = lse2 + ((size_t)b * H + h) * N;
     const int nt = (N + 31) >> 5;                              // tiles (<= 5)
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int g = blockIdx.x;
+    if (g >= G) return;
     FUSED_STAMP(0);
+#ifdef MOFO_ATTN_TRACE_SECOND_ITEM      // trace builds: stamp the block's SECOND item instead of its first (slot 0 stays the kernel start)
+    const int stamp_it = (int)(blockIdx.x + gridDim.x) < G ? 1 : 0;
+#else
+    constexpr int stamp_it = 0;
+#endif
 
-    // ---- this wave's V rows as MFMA B fragments (key on the lane); its K fragments are re-read from the LDS tile per step
-    const int ki = wave * 32 + (lane & 31);
-    const int krow = ki < N ? ki : N - 1;
-    const bool kvalid = ki < N;
+    // stage item gi by LDS-DMA: Q, dO, K tiles into operand set `set`, O tiles into OB (nt x 16 pieces of 8 rows x 128 B; the XOR
+    // swizzle goes on the per-lane SOURCE chunk, DMA writes are lane-linear) and its lse2 row into LSE (pieces of 64 floats) -- dealt
+    // round-robin to the waves, ALL in flight at once
+    // per-lane byte offsets of a piece's source, once per kernel: row (sub * 8 + lane / 8) of a tile, 16-B chunk (lane & 7) ^ swz(row);
+    // a piece then costs ~8 scalar instructions (a wave issues one instruction every ~5 cycles beside a computing partner: the first
+    // persistent versions spent ~35 instructions = 200-300 cycles per piece on 64-bit address arithmetic -- 83 pieces, 23 k cycles)
+    // (five registers: the row part per row stride for row lane / 8 -- the sub * 8 rows go to the uniform base -- and the swizzled
+    // chunk, which has two variants: swz(r0 + 8 sub) = swz(r0) ^ (2 * (sub & 1)))
+    const int r0l = lane >> 3;
+    const int rowq = r0l * ldqkv * 2, rowd = r0l * lddo * 2, rowo = r0l * ldo * 2;
+    const int chb0 = ((lane & 7) ^ swz(r0l)) * 16, chb1 = ((lane & 7) ^ swz(r0l + 8)) * 16;
+    const int nfull = N >> 5;
+    auto stage = [&](int gi, int set, int lz, int first, int stride) {       // lz: see the item loop; pieces first, first + stride, ...
+        const int bi = gi / H, hi = gi - bi * H;
+        const bf16_t* base = qkv + (size_t)bi * N * ldqkv;
+        const bf16_t* qp = base + hi * HD;
+        const bf16_t* kp = base + D + hi * HD;
+        const bf16_t* dop = dout + (size_t)bi * N * lddo + hi * HD;
+        const bf16_t* op = out + (size_t)bi * N * ldo + hi * HD;
+        const float* lp = lse2 + ((size_t)bi * H + hi) * N;
+        auto uni = [](const bf16_t* ptr) {        // a uniform pointer, as the compiler can see it (SGPR pair)
+            const unsigned long long u = (unsigned long long)(size_t)ptr;
+            return (const bf16_t*)(size_t)((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)u) |
+                                           ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(u >> 32)) << 32));
+        };
+        qp = uni(qp), kp = uni(kp), dop = uni(dop), op = uni(op);
+        const unsigned lq = (unsigned)(size_t)LDS_PTR(fsm + set * FUSED_SET), lo = lq + FUSED_NW * TILE, lk = lo + FUSED_NW * TILE;
+        const unsigned lob = (unsigned)(size_t)LDS_PTR(OB), lls = (unsigned)(size_t)LDS_PTR(LSE);
+        const int npc = nt * 16, nls = (nt * 32 + 63) >> 6;
+        for (int pc = first; pc < npc + nls; pc += stride) {
+            if (pc < nfull * 16) {
+                // a full tile: uniform base + the per-lane offset table
+                const int t = pc >> 4, which = (pc >> 2) & 3, sub = pc & 3;
+                const unsigned dst = (which == 0 ? lq : (which == 1 ? lo : (which == 2 ? lk : lob))) + (unsigned)(t * TILE + sub * 1024);
+                const int row0 = t * 32 + sub * 8;
+                const int vo = (which == 1 ? rowd + row0 * lddo * 2 : which == 3 ? rowo + row0 * ldo * 2 : rowq + row0 * ldqkv * 2) + ((sub & 1) ? chb1 : chb0);
+                const bf16_t* sb = which == 0 ? qp : (which == 1 ? dop : (which == 2 ? kp : op));
+                dma_b128_s(sb, vo, (unsigned)__builtin_amdgcn_readfirstlane((int)dst));
+            } else if (pc < npc) {
+                // the ragged last tile: rows clamped per lane
+                const int t = pc >> 4, which = (pc >> 2) & 3, sub = pc & 3;
+                const int rl = sub * 8 + (lane >> 3) + lz;
+                int r = t * 32 + rl;
+                r = r < N ? r : N - 1;
+                const int ch = (lane & 7) ^ swz(rl);
+                const bf16_t* src = which == 0 ? qp + (size_t)r * ldqkv : (which == 1 ? dop + (size_t)r * lddo : (which == 2 ? kp + (size_t)r * ldqkv : op + (size_t)r * ldo));
+                dma_b128(src + ch * 8, (unsigned)__builtin_amdgcn_readfirstlane(
+                                           (int)((which == 0 ? lq : (which == 1 ? lo : (which == 2 ? lk : lob))) + (unsigned)(t * TILE + sub * 1024))));
+            } else {
+                int r = (pc - npc) * 64 + lane + lz;
+                r = r < N ? r : N - 1;
+                dma_b32(lp + r, (unsigned)__builtin_amdgcn_readfirstlane((int)(lls + (unsigned)((pc - npc) * 256))));
+            }
+        }
+    };
+    // this wave's V rows of item gi as MFMA B fragments (key on the lane); its K fragments are re-read from the LDS tile per step
     bf16x8 vf[4];
+    auto load_v = [&](int gi, int lz) {
+        const int bi = gi / H, hi = gi - bi * H;
+        const bf16_t* vp = qkv + (size_t)bi * N * ldqkv + 2 * D + hi * HD;
+        const int kk = wave * 32 + (lane & 31) + lz;
+        const int krow = kk < N ? kk : N - 1;
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
-    // ---- stage the Q, dO, K tiles by LDS-DMA: nt x 12 pieces of 8 rows x 128 B dealt round-robin to the waves, ALL in flight at once
-    // (round 2 staged through registers in two batches: two global round trips plus 15 ds_write passes before the first MFMA --
-    // 41 % of a block's life; the XOR swizzle goes on the per-lane SOURCE chunk, DMA writes are lane-linear)
-    {
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-        const unsigned lq = (unsigned)(size_t)LDS_PTR(QT), lo = (unsigned)(size_t)LDS_PTR(OT), lk = (unsigned)(size_t)LDS_PTR(KT);
-        for (int pc = wave_u; pc < nt * 12; pc += FUSED_NW) {
-            const int t = pc / 12, rem = pc - 12 * t, which = rem >> 2, sub = rem & 3;
-            const int rl = sub * 8 + (lane >> 3);
-            int r = t * 32 + rl;
-            r = r < N ? r : N - 1;
-            const int ch = (lane & 7) ^ swz(rl);
-            const bf16_t* src = which == 0 ? qp + (size_t)r * ldqkv : (which == 1 ? dop + (size_t)r * lddo : kp + (size_t)r * ldqkv);
-            dma_b128(src + ch * 8, (which == 0 ? lq : (which == 1 ? lo : lk)) + (unsigned)(t * TILE + sub * 1024));
-        }
-    }
-    // ---- lse2 and delta = rowsum(dO * O) per query row, from registers while the DMA flies (8 lanes per row, 8 columns each)
-    if (tid < 256) {
-        const int rl = tid >> 3, ch = tid & 7;
-        bf16x8 g[FUSED_NW], o[FUSED_NW];
-        float lv[FUSED_NW];
+        for (int ks = 0; ks < 4; ++ks) vf[ks] = *(const bf16x8*)(vp + (size_t)krow * ldqkv + 16 * ks + 8 * hh);
+    };
+    stage(g, 0, 0, wave_u, FUSED_NT);                          // the first item: all six waves share the issue
 #pragma unroll
-        for (int t = 0; t < FUSED_NW; ++t) {
-            if (t < nt) {
-                const int row = t * 32 + rl;
-                const int r = row < N ? row : N - 1;
-                g[t] = *(const bf16x8*)(dop + (size_t)r * lddo + ch * 8);
-                o[t] = *(const bf16x8*)(op + (size_t)r * ldo + ch * 8);
-                lv[t] = lp[r];
-            }
-        }
-#pragma unroll
-        for (int t = 0; t < FUSED_NW; ++t) {
-            if (t < nt) {
-                const int row = t * 32 + rl;
-                float part = 0.f;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) part += (float)g[t][j] * (float)o[t][j];
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
-                if (ch == 0) {
-                    // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
-                    LD[t * 64 + rl] = row < N ? lv[t] : 1.0e30f;
-                    LD[t * 64 + 32 + rl] = row < N ? part : 0.f;
-                    if (row < N && delta_out) delta_out[((size_t)b * H + h) * N + row] = part;
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces have landed; the barrier covers the others'
-    f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16(), q0 = zero16(), q1 = zero16();
-    FUSED_STAMP(1);
-    __syncthreads();
-    FUSED_STAMP(2);
+    for (int ks = 0; ks < 4; ++ks) vf[ks] = bf16x8{};
+    if (wave_u < FUSED_NW) load_v(g, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this wave's DMA pieces of the first item have landed; barrier A covers the others'
 
     const bool active = wave < nt;                             // waves beyond the last tile only keep the barriers company
     unsigned char* Sw = SC + wave * (32 * SCR);
-    const unsigned char* Kw = KT + wave * TILE;
-    for (int st = 0; st < nt; ++st) {
-        if (active) {
-            int qt = wave + st;
-            qt = qt >= nt ? qt - nt : qt;
-            const unsigned char* Qt = QT + qt * TILE;
-            const unsigned char* Ot = OT + qt * TILE;
-            const float* Lt = LD + qt * 64;
-            const float* Dt = Lt + 32;
-            f32x16 s = zero16(), dpv = zero16();
+    for (int it = 0; g < G; ++it, g += gridDim.x) {
+        // an opaque per-lane zero, new in every iteration: the lane-dependent row offsets of an item's loads are then computed inside
+        // the iteration (a handful of integer operations) instead of being hoisted out of the loop and SPILLED (46 dwords of scratch)
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        const int set = it & 1;
+        const int b = g / H, h = g - b * H;
+        const unsigned char* QT = fsm + set * FUSED_SET;       // [5][TILE]
+        const unsigned char* OT = QT + FUSED_NW * TILE;        // dO tiles
+        const unsigned char* KT = OT + FUSED_NW * TILE;
+        const int ki = wave * 32 + (lane & 31) + lz;
+        const bool kvalid = ki < N;
+        const bool more = g + (int)gridDim.x < G;
+
+        if (it == stamp_it) FUSED_STAMP(1);
+        __syncthreads();                                       // A: this item's tiles, O and lse2 are in LDS (every wave waited for its own pieces);
+        if (it == stamp_it) FUSED_STAMP(2);                           //    every wave has left the previous item's steps
+        // ---- lse2 and delta = rowsum(dO * O) per query row from the LDS tiles (8 lanes per row, one 16-B chunk each)
+        if (tid < 256) {
+            const int rl = (tid >> 3) + lz, ch = tid & 7;
+            const int cho = ((ch ^ swz(rl)) << 4) + rl * RS;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), row_frag(Kw, ks, lane), s, 0, 0, 0);
+            for (int t = 0; t < FUSED_NW; ++t) {
+                if (t < nt) {
+                    const int row = t * 32 + rl;
+                    const bf16x8 gq = *(const bf16x8*)(OT + t * TILE + cho);
+                    const bf16x8 o = *(const bf16x8*)(OB + t * TILE + cho);
+                    float part = 0.f;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
-            float p[16], ds[16];
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-                const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
-                const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * rg + e;
-                    const float pr = fast_exp2(s[r] * c - lv[e]);
-                    p[r] = pr;
-                    ds[r] = pr * (dpv[r] - dv[e]);
+                    for (int j = 0; j < 8; ++j) part += (float)gq[j] * (float)o[j];
+                    part += __shfl_xor(part, 1, 64);
+                    part += __shfl_xor(part, 2, 64);
+                    part += __shfl_xor(part, 4, 64);
+                    if (ch == 0) {
+                        // a query row beyond N contributes nothing: lse2 = +big -> p = exp2(-big) = 0, delta = 0
+                        LD[t * 64 + rl] = row < N ? LSE[row] : 1.0e30f;
+                        LD[t * 64 + 32 + rl] = row < N ? part : 0.f;
+                        if (row < N && delta_out) delta_out[((size_t)b * H + h) * N + row] = part;
+                    }
                 }
             }
-            const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
-            const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
-            // dS tile to the scratch as [key = lane & 31][query]: registers 4 rg .. 4 rg + 3 are queries 8 rg + 4 hh .. + 3;
-            // a key beyond N must not reach dQ (its P is not masked in this orientation)
-            {
-                const int kr = lane & 31;
-                const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
-                const u32x2 z = {0u, 0u};
-                const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
-                                    kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
+        }
+        // the V fragments (issued before the previous item's stores) are waited for HERE, before the next item's DMA joins the counter
+        asm volatile("" :: "v"(vf[0]), "v"(vf[1]), "v"(vf[2]), "v"(vf[3]));
+        f32x16 dk0 = zero16(), dk1 = zero16(), dv0 = zero16(), dv1 = zero16(), q0 = zero16(), q1 = zero16();
+        __syncthreads();                                       // B: LD is written; OB / LSE are read: free for the next item
+        // the next item's 83 DMA pieces: ONE piece per wave and sub-phase (three per step: before the S / dP products, before the
+        // dV / dK products, before the dQ products; 6 waves x 15 sub-phases >= 83).  A wave keeps only about two LDS-DMA pieces of cold
+        // rows in flight (~1.5 k cycles each): issued back to back they block the issuing wave -- all in step 0 cost the steps +6 k
+        // cycles, four per step +3 k per step, and a loader wave alone needed 23-26 k for the 83 (tools/attn_trace.py fused).
+        const int gn = g + (int)gridDim.x;
+
+        const unsigned char* Kw = KT + wave * TILE;
+        for (int st = 0; st < nt; ++st) {
+            if (more) stage(gn, set ^ 1, lz, wave_u + FUSED_NT * (3 * st), 1 << 20);
+            if (active) {
+                int qt = wave + st;
+                qt = qt >= nt ? qt - nt : qt;
+                const unsigned char* Qt = QT + qt * TILE;
+                const unsigned char* Ot = OT + qt * TILE;
+                const float* Lt = LD + qt * 64;
+                const float* Dt = Lt + 32;
+                f32x16 s = zero16(), dpv = zero16();
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
+                for (int ks = 0; ks < 4; ++ks) s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Qt, ks, lane), row_frag(Kw, ks, lane), s, 0, 0, 0);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) dpv = __builtin_amdgcn_mfma_f32_32x32x16_bf16(row_frag(Ot, ks, lane), vf[ks], dpv, 0, 0, 0);
+                float p[16], ds[16];
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const f32x4 lv = *(const f32x4*)(Lt + 8 * rg + 4 * hh);
+                    const f32x4 dv = *(const f32x4*)(Dt + 8 * rg + 4 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * rg + e;
+                        const float pr = fast_exp2(s[r] * c - lv[e]);
+                        p[r] = pr;
+                        ds[r] = pr * (dpv[r] - dv[e]);
+                    }
+                }
+                const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
+                const bf16x8 sf0 = pack_frag(ds, 0), sf1 = pack_frag(ds, 1);
+                // dS tile to the scratch as [key = lane & 31][query]: registers 4 rg .. 4 rg + 3 are queries 8 rg + 4 hh .. + 3;
+                // a key beyond N must not reach dQ (its P is not masked in this orientation)
+                {
+                    const int kr = lane & 31;
+                    const u32x4 w4 = __builtin_bit_cast(u32x4, sf0), w5 = __builtin_bit_cast(u32x4, sf1);
+                    const u32x2 z = {0u, 0u};
+                    const u32x2 w[4] = {kvalid ? u32x2{w4[0], w4[1]} : z, kvalid ? u32x2{w4[2], w4[3]} : z,
+                                        kvalid ? u32x2{w5[0], w5[1]} : z, kvalid ? u32x2{w5[2], w5[3]} : z};
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) *(u32x2*)(Sw + kr * SCR + ((rg ^ (swz(kr) & 3)) << 4) + 8 * hh) = w[rg];
+                }
+                if (more) stage(gn, set ^ 1, lz, wave_u + FUSED_NT * (3 * st + 1), 1 << 20);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 0, lane), pf0, dv0, 0, 0, 0);
+                dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 0, lane), pf1, dv0, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 1, lane), pf0, dv1, 0, 0, 0);
+                dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 1, lane), pf1, dv1, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 0, lane), sf0, dk0, 0, 0, 0);
+                dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
+                dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
             }
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 0, lane), pf0, dv0, 0, 0, 0);
-            dv0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 0, lane), pf1, dv0, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 0, 1, lane), pf0, dv1, 0, 0, 0);
-            dv1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ot, 1, 1, lane), pf1, dv1, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 0, lane), sf0, dk0, 0, 0, 0);
-            dk0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 0, lane), sf1, dk0, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 0, 1, lane), sf0, dk1, 0, 0, 0);
-            dk1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Qt, 1, 1, lane), sf1, dk1, 0, 0, 0);
+            if (it == stamp_it && st == 0) FUSED_STAMP(3);
+            __syncthreads();                                   // every wave's dS of this step is in its scratch
+            if (it == stamp_it && st == 0) FUSED_STAMP(4);
+            if (more) {
+                if (!active) stage(gn, set ^ 1, lz, wave_u + FUSED_NT * (3 * st + 1), 1 << 20);      // a wave without a tile: its second piece of the step
+                stage(gn, set ^ 1, lz, wave_u + FUSED_NT * (3 * st + 2), 1 << 20);
+            }
+            if (active) {
+                // dQ_wave^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query],  j = the wave that worked on this query tile
+                int j = wave - st;
+                j = j < 0 ? j + nt : j;
+                const unsigned char* Sj = SC + j * (32 * SCR);
+                const unsigned char* Kj = KT + j * TILE;
+                const bf16x8 t0 = tr_frag_scratch(Sj, 0, lane), t1 = tr_frag_scratch(Sj, 1, lane);
+                q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 0, lane), t0, q0, 0, 0, 0);
+                q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 0, lane), t1, q0, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 1, lane), t0, q1, 0, 0, 0);
+                q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 1, lane), t1, q1, 0, 0, 0);
+            }
+            if (st + 1 < nt) __syncthreads();                  // the scratches are free again (the next item's first use is behind its barriers)
+            if (it == stamp_it && st == 0) FUSED_STAMP(5);
         }
-        if (st == 0) FUSED_STAMP(3);
-        __syncthreads();                                       // every wave's dS of this step is in its scratch
-        if (st == 0) FUSED_STAMP(4);
+        if (it == stamp_it) FUSED_STAMP(6);
+#ifdef MOFO_ATTN_TRACE_SECOND_ITEM
+        if (it + 1 == stamp_it) FUSED_STAMP(0);                // (debug) slot 0 := end of the first item's steps
+#endif
+        if (more) {
+            // the loader wave's DMA pieces of the next item were issued a whole item ago: its wait is free; a computing wave requests
+            // the next item's V fragments BEFORE this item's stores enter the in-order counter
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#ifdef MOFO_ATTN_TRACE_SECOND_ITEM
+            if (it + 1 == stamp_it) FUSED_STAMP(7);            // (debug) slot 7 := after that wait
+#endif
+            if (wave_u < FUSED_NW) load_v(g + gridDim.x, lz);
+        }
+        // write-out through LDS: the accumulators hold D[d][row] with the row on the lane, so a direct store is 32 rows x 8 B per
+        // instruction (48 scattered store instructions per wave: ~8 k cycles of issue that a persistent block pays before its next
+        // item).  Each wave transposes into its own three 4-KiB tiles of THIS item's operand set (dead after the barrier below) and
+        // writes whole 128-B rows, 8 rows per instruction.
+        __syncthreads();                                       // every wave has read its last Q / K / dO fragments of this set
         if (active) {
-            // dQ_wave^T [d][query] += K_j^T [d][key] . dS_(wave, j) [key][query],  j = the wave that worked on this query tile
-            int j = wave - st;
-            j = j < 0 ? j + nt : j;
-            const unsigned char* Sj = SC + j * (32 * SCR);
-            const unsigned char* Kj = KT + j * TILE;
-            const bf16x8 t0 = tr_frag_scratch(Sj, 0, lane), t1 = tr_frag_scratch(Sj, 1, lane);
-            q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 0, lane), t0, q0, 0, 0, 0);
-            q0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 0, lane), t1, q0, 0, 0, 0);
-            q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 0, 1, lane), t0, q1, 0, 0, 0);
-            q1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Kj, 1, 1, lane), t1, q1, 0, 0, 0);
+            unsigned char* w0 = const_cast<unsigned char*>(QT) + wave * TILE;
+            unsigned char* w1 = const_cast<unsigned char*>(OT) + wave * TILE;
+            unsigned char* w2 = const_cast<unsigned char*>(KT) + wave * TILE;
+            stage_T(w0, q0, q1, scale, lane);
+            stage_T(w1, dk0, dk1, scale, lane);
+            stage_T(w2, dv0, dv1, 1.0f, lane);
+            bf16_t* dbase = dqkv + ((size_t)b * N + wave * 32) * lddqkv + h * HD;
+            const int rows = N - wave * 32;                    // valid rows of this tile (>= 1 for an active wave)
+            store_rows(dbase, lddqkv, w0, rows, lane);
+            store_rows(dbase + D, lddqkv, w1, rows, lane);
+            store_rows(dbase + 2 * D, lddqkv, w2, rows, lane);
         }
-        if (st + 1 < nt) __syncthreads();                      // the scratches are free again
-        if (st == 0) FUSED_STAMP(5);
     }
-    FUSED_STAMP(6);
-    if (!active) return;
-    if (kvalid) {       // query tile `wave` has the same rows as key tile `wave`
-        bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
-        store_T(drow, q0, q1, scale, hh);
-        store_T(drow + D, dk0, dk1, scale, hh);
-        store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
-    }
+#ifndef MOFO_ATTN_TRACE_SECOND_ITEM
+    FUSED_STAMP(7);                                            // end of the block's last item
+#endif
 }
 
 // delta[b,h,q] = sum_d dO[q, h*64+d] * O[q, h*64+d]: 8 lanes per (token, head), 16-B loads, 3-step shuffle reduce.
@@ -1069,7 +1209,16 @@ extern "C" int mofo_attention_bwd(const void* qkv, int ldqkv, const void* out, i
             attr_set = true;
         }
         const float c = scale * 1.4426950408889634f;
-        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(8 * ceil_div(B * H, 8)), dim3(FUSED_NW * 64), FUSED_SMEM, (hipStream_t)stream,
+        static int ncu = 0;                                     // one 5-wave block per CU (217 VGPRs): a grid of at most that many, persistent over the items
+        if (!ncu) {
+            int dev = 0;
+            hipDeviceProp_t pr;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess || pr.multiProcessorCount <= 0)
+                MOFO_FAIL(MOFO_ERUNTIME, "mofo_attention_bwd: cannot read the device's CU count");
+            ncu = pr.multiProcessorCount;
+        }
+        const int items = B * H;
+        hipLaunchKernelGGL(attn_bwd_fused_kernel, dim3(items < ncu ? items : ncu), dim3(FUSED_NT * 64), FUSED_SMEM, (hipStream_t)stream,
                            (const bf16_t*)qkv, ldqkv, B * H, N, H, c, scale, (const bf16_t*)out, ldo, (const bf16_t*)dout, lddo, lse2, delta,
                            (bf16_t*)dqkv, lddqkv);
         MOFO_CHECK_LAUNCH("mofo_attention_bwd(fused)");

@@ -681,6 +681,50 @@ def test_attention_fwd_bwd(dev, B, N, H):
     assert torch.allclose(delta, want, rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("B,N,H", [(32, 160, 12), (50, 100, 6), (100, 160, 7), (9, 33, 30)])
+def test_attention_bwd_short_sequences_persistent(dev, B, N, H):
+    """the one-kernel backward of short sequences is persistent over the (clip, head) items (grid capped at the CU count, the next
+    item's tiles prefetched into a second LDS operand set): 1.5 items per block (the encoder at B = 32), ragged tiles with
+    1.2 items per block, 2.7 items per block (three iterations: both operand sets reused), 33-token sequences -- every item against
+    the three-kernel form of the same library (MOFO_ATTN_NO_FUSED_BWD=1), which has its own test against fp32 torch"""
+    from mofo_amd import ops
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _rand((B * N, 3 * D), dev, 21, 1.5)
+    out = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
+    dout = _rand((B * N, D), dev, 22)
+    got = torch.full_like(qkv, float("nan"))
+    delta = torch.full((B * H * N,), float("nan"), dtype=F32, device=dev)
+    ops.attention_bwd(qkv, out, dout, lse2, B, N, H, scale, got, delta)
+    ref = torch.empty_like(qkv)
+    d2 = torch.empty_like(delta)
+    ops.attention_delta(out, dout, B, N, H, d2)
+    ops.attention_bwd_dkv(qkv, dout, lse2, d2, B, N, H, scale, ref)
+    ops.attention_bwd_dq(qkv, dout, lse2, d2, B, N, H, scale, ref)
+    assert torch.isfinite(got).all() and torch.isfinite(delta).all()
+    assert torch.allclose(delta, d2, rtol=1e-5, atol=1e-5)
+    g3, r3 = got.view(B, N, 3, H, 64).float(), ref.view(B, N, 3, H, 64).float()
+    for part, name in enumerate(("dq", "dk", "dv")):
+        # per (clip, head) item: a block that mixed up its items or read a half-landed operand set is off by O(1) in that item
+        num = (g3[:, :, part] - r3[:, :, part]).pow(2).sum(dim=(1, 3)).sqrt()
+        den = r3[:, :, part].pow(2).sum(dim=(1, 3)).sqrt() + 1e-20
+        assert float((num / den).max()) < 1.5e-2, name
+    # no atomics, no race between an item's steps and the next item's LDS-DMA: bit-identical on every further launch, also with a
+    # copy stream keeping HBM busy beside it
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    for rep in range(12):
+        again = torch.full_like(qkv, float("nan"))
+        if rep % 2:
+            with torch.cuda.stream(side):
+                big.copy_(big.flip(0))
+        ops.attention_bwd(qkv, out, dout, lse2, B, N, H, scale, again, delta)
+        assert torch.equal(again, got), rep
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("B,N,H,qb", [(2, 1568, 2, 160), (1, 1561, 3, 168), (2, 224, 2, 40), (3, 100, 2, 32), (2, 160, 1, 16)])
 def test_attention_query_range(dev, B, N, H, qb):
     """The *_range entries (queries q_begin .. N - 1 of every clip only, out / dout compact): what the last decoder block runs, whose

@@ -58,6 +58,14 @@ buf = np.zeros((1 << 15) * 8, dtype=np.uint64)
 lib.mofo_debug_attn_trace_read.argtypes = [C.c_void_p, C.c_size_t]; lib.mofo_debug_attn_trace_read.restype = C.c_int
 assert lib.mofo_debug_attn_trace_read(buf.ctypes.data, buf.nbytes) == 0
 t = buf.reshape(-1, 8)
+if kind == "fused":     # persistent over the (clip, head) items: slot 7 = end of the block's last item
+    full = t[t[:, 0] > 0].astype(np.int64)
+    if "SECOND_ITEM" in os.environ.get("MOFO_TRACE_DEFS", ""):
+        two = full[full[:, 7] > 0]
+        print(f"second-item build: end of item 1's steps -> after the DMA wait: p50 {np.median(two[:, 7] - two[:, 0]):.0f} clk ({len(two)} two-item blocks)")
+    life = full[:, 7] - full[:, 0]
+    print(f"block life (all its items): p10 {np.percentile(life, 10):.0f}  p50 {np.percentile(life, 50):.0f}  p90 {np.percentile(life, 90):.0f}  max {life.max()} clk; "
+          f"kernel span {full[:, 7].max() - full[:, 0].min()} clk; blocks starting within {full[:, 0].max() - full[:, 0].min()} clk")
 t = t[t[:, 0] > 0][:, :7].astype(np.int64)
 d = np.diff(t, axis=1)
 print(f"{len(t)} blocks")
