@@ -984,9 +984,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
             const char* e = getenv("MOFO_GEMM_KSPLIT");
             ksplit_on = e ? atoi(e) : 1;
         }
-        const char* emk = getenv("MOFO_GEMM_KSPLIT_MINK");     // read per call (A/B in one process); default: reductions of >= 1536
-        const int ksplit_mink = emk ? atoi(emk) : 1536;
-        if (mi == 2 && can_persist && total <= 512 && p.K >= ksplit_mink && ((forced < 0 && ksplit_on) || forced == 3)) {
+        if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && ((forced < 0 && ksplit_on) || forced == 3)) {
             hipLaunchKernelGGL((gemm_ksplit_kernel<LA, LB, EPI>), dim3(total), dim3(512), 0, s, p, total);
             ROUTE(ROUTE_KSPLIT);
         } else if (mi == 8) {
