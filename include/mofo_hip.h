@@ -146,6 +146,10 @@ int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, in
                                 int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
 int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                  int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
+/* The dQ pass that also computes delta = rowsum(dO * O) of its query rows (out: laid out like dout) and WRITES it to delta_out for the
+ * dK/dV pass: call it first, then mofo_attention_bwd_dkv[_range] on the same stream; mofo_attention_delta[_range] is then not needed. */
+int mofo_attention_bwd_dq_delta_range(const void* qkv, int ldqkv, const void* out, int ldo, const void* dout, int lddo, const float* lse2,
+                                      float* delta_out, int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
 
 /* ---- RCCL communicator: the stand-alone route to the ONE collective of the path -- the per-step gradient
  * all-reduce of run_mae_pretraining.py:225-227 (DDP) over the group of utils.py:289-294 -- for callers that bind this library

@@ -55,6 +55,7 @@ _SIGS = {
     "mofo_attention_fwd_range": (_i, [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
     "mofo_attention_delta_range": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mofo_attention_bwd_dq_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
+    "mofo_attention_bwd_dq_delta_range": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "mofo_attention_bwd_dkv_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "mofo_mask_to_indices": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "mofo_tube_masks": (_i, [C.c_uint, C.c_uint, _i, _i, _i, _i, _vp, _vp]),

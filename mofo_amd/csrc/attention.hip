@@ -181,7 +181,22 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) dof[ks] = *(const bf16x8*)(dop + 16 * ks + 8 * hh);
         L2 = lse2[((size_t)b * H + h) * N + qrow];
-        dl = delta[((size_t)b * H + h) * N + qrow];     // rowsum(dO * O), from attn_delta_kernel
+        if (out) {
+            // delta = rowsum(dO * O) computed HERE from the row's O (this lane holds 32 of the row's 64 dO values: the other half sits
+            // on lane ^ 32) and WRITTEN for the dK/dV pass that follows: no separate delta kernel (19 us per decoder layer)
+            const bf16_t* orow = out + ((size_t)b * nq + (qrow - qb)) * ldo + h * HD;
+            float part = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 ov = *(const bf16x8*)(orow + 16 * ks + 8 * hh);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) part += (float)dof[ks][j] * (float)ov[j];
+            }
+            dl = part + __shfl_xor(part, 32, 64);
+            if (qvalid && hh == 0) delta[((size_t)b * H + h) * N + qi] = dl;
+        } else {
+            dl = delta[((size_t)b * H + h) * N + qrow];     // rowsum(dO * O), from attn_delta_kernel
+        }
     }
     // dQ pass: the dP accumulator STARTS at -delta (a lane holds 16 keys of ONE query, so the tuple is 16 copies of the lane's
     // value, kept for the whole kernel: 16 registers for 16 subtractions per tile; exact up to the order of f32 additions;
@@ -1162,6 +1177,29 @@ extern "C" int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const voi
         default: LAUNCH_Q(4, 1); break;
     }
     MOFO_CHECK_LAUNCH("mofo_attention_bwd_dq");
+    return MOFO_OK;
+}
+
+// The dQ pass that also COMPUTES delta = rowsum(dO * O) for its query rows (from `out`, laid out like `dout`) and writes it to
+// `delta_out` for the dK/dV pass: run it BEFORE mofo_attention_bwd_dkv[_range] on the same stream and skip mofo_attention_delta.
+extern "C" int mofo_attention_bwd_dq_delta_range(const void* qkv, int ldqkv, const void* out_in, int ldo_in, const void* dout, int lddo,
+                                                 const float* lse2_in, float* delta_out, int B, int N, int H, float scale, int q_begin,
+                                                 void* dqkv, int lddqkv, void* stream) {
+    int rc = bwd_check("mofo_attention_bwd_dq_delta", qkv, ldqkv, dout, lddo, lse2_in, delta_out, B, N, H, dqkv, lddqkv);
+    if (rc) return rc;
+    if ((rc = check_range("mofo_attention_bwd_dq_delta", N, q_begin))) return rc;
+    if (!out_in || ldo_in % 8 || ldo_in < H * 64) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_bwd_dq_delta: bad out / ldo");
+    hipStream_t s = (hipStream_t)stream;
+    const float c = scale * 1.4426950408889634f;
+    float* lse2 = const_cast<float*>(lse2_in);
+    float* delta = delta_out;
+    void* out = const_cast<void*>(out_in); int ldo = ldo_in;
+    switch (pick_nw(N)) {
+        case 7: LAUNCH_Q(7, 1); break;
+        case 5: LAUNCH_Q(5, 1); break;
+        default: LAUNCH_Q(4, 1); break;
+    }
+    MOFO_CHECK_LAUNCH("mofo_attention_bwd_dq_delta");
     return MOFO_OK;
 }
 

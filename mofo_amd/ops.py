@@ -430,6 +430,14 @@ def attention_bwd_dq(qkv, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
          B, N, H, scale, q_begin, _p(dqkv), _ld(dqkv))
 
 
+def attention_bwd_dq_delta(qkv, out, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
+    """the dQ pass that computes delta = rowsum(dO * O) itself and WRITES it (rows q_begin .. N - 1) for attention_bwd_dkv, which must
+    follow on the same stream; attention_delta is then not needed"""
+    _attn_bwd_chk(qkv, out, dout, lse2, B, N, H, dqkv, delta, q_begin)
+    _run("mofo_attention_bwd_dq_delta_range", ("attn_bwd_dq",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), _p(out), _ld(out), _p(dout), _ld(dout),
+         _p(lse2), _p(delta), B, N, H, scale, q_begin, _p(dqkv), _ld(dqkv))
+
+
 def attention_bwd_dkv(qkv, dout, lse2, delta, B, N, H, scale, dqkv, q_begin=0):
     _attn_bwd_chk(qkv, None, dout, lse2, B, N, H, dqkv, delta, q_begin)
     _run("mofo_attention_bwd_dkv_range", ("attn_bwd_dkv",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), _p(dout), _ld(dout), _p(lse2), _p(delta),

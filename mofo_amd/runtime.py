@@ -600,11 +600,10 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dh1, W.fc1, C.dxln)
         self._ln_bwd(C.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, C.dx0, None, C.dxbB, W.g_ln2w, W.g_ln2b)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dxbB, W.proj, C.dao)
-        ops.attention_delta(L.ao, C.dao, B, n, H, S.delta, q_begin=qb)
         dq_dead = T.dqkv.view(B, n, 3 * D)[:, :qb, :D]
         ops.host_op(lambda: dq_dead.zero_())
+        ops.attention_bwd_dq_delta(L.qkv, L.ao, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
         ops.attention_bwd_dkv(L.qkv, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
-        ops.attention_bwd_dq(L.qkv, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
         self._ln_bwd(S.dxln, x_in, W.ln1w, L.mean1, L.rstd1, C.dxbB, None, dxb_in, W.g_ln1w, W.g_ln1b, dres_rows=(n, qb))
         S.pending += [(C.dx0, L.g, W.g_fc2, W.g_fc2b, (0, 0)), (C.dh1, L.xln2, W.g_fc1, W.g_fc1b, (0, 0)),
@@ -689,10 +688,14 @@ class PretrainRuntime:
             if n <= 160:
                 # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
                 ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
-            else:
+            elif os.environ.get("MOFO_ATTN_DELTA_KERNEL", "0") == "1":
                 ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
                 ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
                 ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+            else:
+                # the dQ pass computes delta = rowsum(dO * O) on the way and leaves it for the dK/dV pass (no delta kernel: 19 us per layer)
+                ops.attention_bwd_dq_delta(L.qkv, L.ao, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+                ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
         if share is not None:
             # the adjoint of the forward's row sharing: qkv gradient and residual gradient summed per cat row (visible rows copied,
             # position rows added over the clips that mask the position, f32), then dgrad / LayerNorm backward / weight gradient on

@@ -725,6 +725,37 @@ def test_attention_bwd_short_sequences_persistent(dev, B, N, H):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("B,N,H,qb", [(2, 1568, 2, 0), (2, 1568, 2, 160), (1, 1561, 3, 168), (3, 100, 2, 0), (2, 160, 1, 16)])
+def test_attention_dq_pass_computes_delta(dev, B, N, H, qb):
+    """mofo_attention_bwd_dq_delta_range: the dQ pass computes delta = rowsum(dO * O) of its query rows itself and leaves it for the
+    dK/dV pass (no delta kernel).  Same delta as mofo_attention_delta up to the order of f32 additions, same dq / dk / dv as the
+    three-call sequence to that precision, rows of delta below q_begin untouched, long / short / ragged sequences."""
+    from mofo_amd import ops
+    D = H * 64
+    scale = 64 ** -0.5
+    qkv = _rand((B * N, 3 * D), dev, 31, 1.5)
+    out_full = torch.empty(B * N, D, dtype=BF16, device=dev)
+    lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, scale, out_full, lse2)
+    nq = N - qb
+    out = out_full.view(B, N, D)[:, qb:].reshape(B * nq, D).contiguous()
+    dout = _rand((B * nq, D), dev, 32)
+    d_ref = torch.full((B * H * N,), 7.0, dtype=F32, device=dev)
+    ref = torch.zeros_like(qkv)
+    ops.attention_delta(out, dout, B, N, H, d_ref, q_begin=qb)
+    ops.attention_bwd_dkv(qkv, dout, lse2, d_ref, B, N, H, scale, ref, q_begin=qb)
+    ops.attention_bwd_dq(qkv, dout, lse2, d_ref, B, N, H, scale, ref, q_begin=qb)
+    d_got = torch.full((B * H * N,), 7.0, dtype=F32, device=dev)
+    got = torch.zeros_like(qkv)
+    ops.attention_bwd_dq_delta(qkv, out, dout, lse2, d_got, B, N, H, scale, got, q_begin=qb)
+    ops.attention_bwd_dkv(qkv, dout, lse2, d_got, B, N, H, scale, got, q_begin=qb)
+    assert torch.allclose(d_got, d_ref, rtol=1e-5, atol=1e-5)
+    if qb:
+        assert torch.all(d_got.view(B, H, N)[:, :, :qb] == 7.0)           # delta of the skipped queries: not written
+    for name, sl in (("dq", slice(0, D)), ("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
+        assert _rel(got[:, sl], ref[:, sl]) < 2e-3, name
+
+
 @pytest.mark.parametrize("B,N,H,qb", [(2, 1568, 2, 160), (1, 1561, 3, 168), (2, 224, 2, 40), (3, 100, 2, 32), (2, 160, 1, 16)])
 def test_attention_query_range(dev, B, N, H, qb):
     """The *_range entries (queries q_begin .. N - 1 of every clip only, out / dout compact): what the last decoder block runs, whose
