@@ -987,6 +987,9 @@ def test_bench_two_ranks_rehearsal(dev):
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["global_batch"] == 8 and out["config"]["parallelism"] == "dp2"
     assert out["value"] == pytest.approx(8 / out["ms_per_step"] * 1e3, rel=1e-3) and math.isfinite(out["config"]["final_loss"])
     assert "cpu_baseline" not in out and "roofline" in out
+    # the exchange checked itself (dist.GradSync.value_check) and every rank reported its exposed all-reduce time
+    assert out["config"]["allreduce_value_check"] == "ok" and out["config"]["allreduce_value_check_max_rel"] < 1e-4
+    assert len(out["config"]["exposed_allreduce_ms_per_rank"]) == 2
 
 
 def test_bench_self_launch_two_ranks(dev):
