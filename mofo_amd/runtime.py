@@ -300,6 +300,13 @@ class PretrainRuntime:
         if dec_prefix is not None:
             self.decW = [self._block_weights(f"{dec_prefix}blocks.{i}.") for i in range(dims.dec_depth)]
         self.segment_hook: Optional[Callable[[int, int, int], None]] = None  # (segment id, lo, hi) as gradient ranges complete
+        # (set before the gradient buckets are planned: their sizes follow the group size)
+        # encoder blocks per grouped weight-gradient launch: MOFO_WGRAD_BLOCKS, else the smallest group that fills whole rounds of the
+        # 768 resident 128 x 128 tiles best (ViT-B: 432 tiles per block -> 3 blocks = 1.69 rounds; ViT-L: 768 per block -> 1 block = one
+        # round exactly: 53.9 / 53.1 / 51.4 ms per step with 3 / 2 / 1 blocks per launch)
+        self.wgrad_blocks = max(1, min(3, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
+            _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio))
+        self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         # forward_only: the fine-tune / feature-extraction forward (modeling_finetune.py) -- no gradient buckets to plan
         self.segments = [] if forward_only else self.plan_segments()
         # The DECODER's residual stream is kept in bf16 (x_full, x_mid, x_out): its GEMMs reduce over 384 / 1536 and are bound
@@ -333,13 +340,6 @@ class PretrainRuntime:
                     W.site = 2 * i
                 self._fp8_calibrated = False
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
-        # encoder blocks whose weight gradients share one grouped launch (1..3; mofo_gemm_grouped takes 12 problems)
-        # encoder blocks per grouped weight-gradient launch: MOFO_WGRAD_BLOCKS, else the smallest group that fills whole rounds of the
-        # 768 resident 128 x 128 tiles best (ViT-B: 432 tiles per block -> 3 blocks = 1.69 rounds; ViT-L: 768 per block -> 1 block = one
-        # round exactly: 53.9 / 53.1 / 51.4 ms per step with 3 / 2 / 1 blocks per launch)
-        self.wgrad_blocks = max(1, min(3, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
-            _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio))
-        self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self.side2 = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
         self._seg_events = [torch.cuda.Event() for _ in range(8)] if self.dev.type == "cuda" else []
@@ -752,13 +752,24 @@ class PretrainRuntime:
                 S.used[k] = False
 
     @staticmethod
-    def _enc_buckets(depth: int) -> List[int]:
+    def _enc_buckets(depth: int, group: int = 1) -> List[int]:
         """encoder blocks per gradient bucket, from the top block down: shrinking buckets (12 -> 5, 3, 2, 1, 1) so that the
         all-reduce left exposed after the last weight gradient is the smallest one (one block + patch embed: 33 MB at
-        ViT-B instead of 85 MB with equal buckets of three), while the early, fully overlapped ones stay large"""
+        ViT-B instead of 85 MB with equal buckets of three), while the early, fully overlapped ones stay large.  With
+        ``group`` > 1 encoder blocks per grouped weight-gradient launch the large early buckets are whole groups (12, group 3 ->
+        6, 3, 2, 1): a bucket end cuts a group short (x1 / x2 groups run at 812 / 834 TFLOP/s against 963 for x3) and every
+        bucket costs ~0.08 ms of hand-over (one rank under RCCL, ms per step: 5,3,2,1,1 11.80-11.83 | 6,3,2,1 11.71 | 3,3,3,3 11.68 |
+        6,6 11.57 | 12 11.49 | no exchange 11.30 -- the last three expose 85 / 170 / 340 MB of all-reduce after the backward)"""
+        env = os.environ.get("MOFO_ENC_BUCKETS")          # experiment switch: "6,3,2,1" (must sum to the depth)
+        if env:
+            sizes = [int(x) for x in env.split(",")]
+            if sum(sizes) == depth and all(x > 0 for x in sizes):
+                return sizes
         sizes, rem = [], depth
         while rem > 0:
             take = max(1, min(rem, -(-rem * 2 // 5)))
+            if group > 1 and rem > 2 * group and take % group:
+                take = min(rem, -(-take // group) * group)
             sizes.append(take)
             rem -= take
         return sizes
@@ -781,7 +792,7 @@ class PretrainRuntime:
             p = self.enc_prefix
             cur = [p + "norm.weight", p + "norm.bias"]
             i = d.enc_depth - 1
-            buckets = self._enc_buckets(d.enc_depth)
+            buckets = self._enc_buckets(d.enc_depth, self.wgrad_blocks)
             for bi, nb in enumerate(buckets):
                 for _ in range(nb):
                     cur += self.encW[i].names
@@ -877,7 +888,7 @@ class PretrainRuntime:
         j = 0
         # bucket boundaries (block index after which a gradient range is complete), as plan_segments laid them out
         ends, i_end = set(), d.enc_depth
-        for nb in self._enc_buckets(d.enc_depth)[:-1]:
+        for nb in self._enc_buckets(d.enc_depth, self.wgrad_blocks)[:-1]:
             i_end -= nb
             ends.add(i_end)
         R = len(S.ring)

@@ -194,6 +194,8 @@ def test_gradient_segments_tile_the_buffer():
     rt, st = _cpu_runtime(model)
     segs = rt.segments
     assert rt._enc_buckets(12) == [5, 3, 2, 1, 1] and rt._enc_buckets(5) == [2, 2, 1]   # shrinking: the exposed one is the smallest
+    assert rt._enc_buckets(12, 3) == [6, 3, 2, 1] and rt._enc_buckets(5, 3) == [2, 2, 1] and rt._enc_buckets(24, 1) == rt._enc_buckets(24)
+    assert rt._enc_buckets(24, 3) == [12, 6, 3, 2, 1] and all(sum(rt._enc_buckets(n, g)) == n for n in range(1, 40) for g in (1, 2, 3))
     assert len(segs) == 4                                             # decoder group + 3 encoder groups (5 blocks -> 2 + 2 + 1)
     ranges = sorted(segs)
     assert ranges[0][0] == 0 and ranges[-1][1] == st.total
