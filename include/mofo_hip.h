@@ -18,7 +18,9 @@
 extern "C" {
 #endif
 
-#define MOFO_ABI_VERSION 1
+/* 2 (round 5): mofo_attention_delta_zero_dq and mofo_attention_bwd_onepass are gone (round 4), mofo_gemm_grouped_plan is new and
+ * mofo_gemm_grouped takes up to 32 weight-gradient problems; INTEGRATION.md lists every change of the exported set. */
+#define MOFO_ABI_VERSION 2
 
 /* ---- library ---- */
 int mofo_version(void);
@@ -66,12 +68,19 @@ typedef struct mofo_gemm_args {
     const float* b_scale_inv;
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
-/* up to 13 problems of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of three transformer blocks
+/* up to 13 problems (32 for TN + F32 weight-gradient groups) of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of three transformer blocks
  * and the patch embed's) */
 int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
+/* Weight-gradient groups (every problem TN + F32; up to 32 of them) may be routed to the 256 x 128 ring kernel, which deals the last,
+ * partial round of tiles to ALL compute units in chunks of the reduction: a tile shared by several workgroups is summed with f32
+ * atomics, so its destination must hold zeros (or the running sum) before the launch.  This host-only query tells the caller which:
+ * shared[i] = 1 when problem i's C may receive atomic adds (always so for splits > 1 / accumulate), 0 when every element of C is
+ * plainly stored exactly once.  Returns 1 when the group goes to the ring kernel, 0 otherwise, < 0 on error.  Same routing
+ * decision as mofo_gemm_grouped with the same arguments and environment. */
+int mofo_gemm_grouped_plan(const mofo_gemm_args* args, int count, int* shared);
 /* Diagnostics (host side, no device work): launches per main-loop family since the last reset -- out[0] one tile per block,
  * [1] persistent 64/128-row tiles, [2] persistent 256-row tiles, [3] in-block split-K, [4] the 256 x 256 counted-vmcnt kernel,
- * [5] e4m3, [6] one 128 x 128 tile per CU with the reduction halved over two wave groups, [7] reserved.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
+ * [5] e4m3, [6] one 128 x 128 tile per CU with the reduction halved over two wave groups, [7] the 256 x 128 three-stage ring kernel.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
 int mofo_gemm_route_counts(long long* out, int n, int reset);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */

@@ -35,6 +35,7 @@ _SIGS = {
     "mofo_last_error": (C.c_char_p, []),
     "mofo_gemm": (_i, [C.POINTER(GemmArgs), _vp]),
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
+    "mofo_gemm_grouped_plan": (_i, [C.POINTER(GemmArgs), _i, C.POINTER(_i)]),
     "mofo_gemm_route_counts": (_i, [C.POINTER(_ll), _i, _i]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
@@ -101,7 +102,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mofo_version() != 1:
+        if lib.mofo_version() != 2:
             raise RuntimeError("libmofo_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -106,9 +106,55 @@ __device__ __forceinline__ void srd_lane_offsets(int ld, int lane, int& v0, int&
         v1 = (kq * ld + g1 * 8) * 2;
     }
 }
+// LDS-DMA piece issued from INLINE ASM: 1 KiB = 64 lanes x 16 B, global -> LDS without a VGPR round trip, for the kernels with a
+// COUNTED vmcnt pipeline (gemm8.h, gemm_k2.h, gemm_r3.h).
+// WHY NOT THE BUILTIN there (found in round 5 from the disassembly): hipcc's wait-count pass knows that `raw_ptr_buffer_load_lds`
+// writes LDS, and in front of every LDS read whose memory operand carries no alias scope it puts a wait for "every LDS-DMA so far" =
+// `s_waitcnt vmcnt(0)`.  Plain `ds_read_b128` loads carry a scope (no wait); the transposing `ds_read_b64_tr_b16` builtin does not,
+// so every kernel that reads a reduction-strided (COL) operand drained its whole LDS-DMA pipeline once per read group, whatever the
+// counted `vmcnt(N)` in the source said (gemm8 TN: 15 such waits in the K loop, NN: 4; gemm_k2 NN: 1).  An LDS-DMA the compiler cannot
+// see sets no such score: the counted waits in the source are then the only ones (they were designed to be sufficient: RAW / WAR rules
+// in each kernel's header).  hipcc's own vmcnt bookkeeping for the loads and stores it does see stays safe: the counter is in
+// order, so unknown extra operations in the queue only make its `vmcnt(N)` wait for more.
+// M0 (the LDS destination base) is saved and restored inside the statement (hipcc reserves it); `s_nop 4` covers a descriptor /
+// offset SGPR freshly written by a VALU (v_readfirstlane); `s_nop 0` the M0 write -> LDS-DMA hazard.
+// Measured (profiles/r05_dma_asm_ab.txt): the ring kernel's weight gradients 869 -> 1 064 TFLOP/s at 4096^3 with the asm form; gemm_k2's
+// NN shapes are 10 % SLOWER with it (its inserted wait only shortens a two-stage ring, and an asm statement is a scheduling barrier
+// the builtin is not), so gemm_k2 and gemm8 keep the builtin (MOFO_DMA_ASM_K2 / _G8 = 1 builds them with the asm form).
+// LEAN: M0 is not saved / restored and no VALU -> SGPR pad is issued -- for kernels that contain no compiler-visible use of M0 and
+// whose descriptor / offsets are SALU results (kernel arguments, blockIdx and readfirstlane'd wave ids from the prologue).
+#ifndef MOFO_DMA_ASM
+#define MOFO_DMA_ASM 1
+#endif
+#ifndef MOFO_DMA_ASM_K2
+#define MOFO_DMA_ASM_K2 0
+#endif
+#ifndef MOFO_DMA_ASM_G8
+#define MOFO_DMA_ASM_G8 0
+#endif
+template <bool LEAN = false>
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, unsigned char* lds_dst, int voff, unsigned soff) {
+#if MOFO_DMA_ASM
+    if constexpr (LEAN) {
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds"
+                     :
+                     : "s"((unsigned)(unsigned long long)LDS_PTR(lds_dst)), "v"(voff), "s"(rsrc), "s"(soff)
+                     : "memory");
+    } else {
+        unsigned keep;
+        asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "s"((unsigned)(unsigned long long)LDS_PTR(lds_dst)), "v"(voff), "s"(rsrc), "s"(soff)
+                     : "memory");
+    }
+#else
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_dst), 16, voff, (int)soff, 0, 0);
+#endif
+}
+
 // AUX = 2: non-temporal load (an operand this launch streams ONCE, e.g. the activation rows of a tall forward GEMM) so that
 // it does not displace the weight panel every block of the XCD re-reads from its 4 MiB L2.
-template <int LAYOUT, int NI, int AUX = 0>
+template <int LAYOUT, int NI, int AUX = 0, bool ASM = false>
 __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int v0, int v1, int ld, int d0, int k0,
                                                unsigned char* lds_tile, int wave_u) {
 #pragma unroll
@@ -118,11 +164,13 @@ __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int 
             // unsigned: a tile row offset past the operand (ragged last tile) may exceed INT_MAX bytes for operands close to
             // the 2 GiB extent limit that fill_problem enforces; the SRD range check then reads zeros
             const unsigned soff = ((unsigned)(d0 + 8 * i) * (unsigned)ld + (unsigned)k0) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, AUX);
+            if constexpr (ASM) lds_dma16<false>(rsrc, lds_tile + i * 1024, v0, soff);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, AUX);
         } else {
             static_assert(LAYOUT == OPL_ROW || NI == 4, "piece parity below assumes 4 pieces per wave");
             const unsigned soff = ((unsigned)(k0 + 4 * i) * (unsigned)ld + (unsigned)d0) * 2u;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, (int)soff, 0, AUX);
+            if constexpr (ASM) lds_dma16<false>(rsrc, lds_tile + i * 1024, ((j >> 1) & 1) ? v1 : v0, soff);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, ((j >> 1) & 1) ? v1 : v0, (int)soff, 0, AUX);
         }
     }
 }
@@ -899,6 +947,7 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
 
 #include "gemm8.h"
 #include "gemm_k2.h"
+#include "gemm_r3.h"
 
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
 // (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
@@ -934,7 +983,7 @@ static bool gemm8_has(int op, int epi) {
 
 // launches per kernel family since the last reset (mofo_gemm_route_counts): tests assert that a model-level parity run really went
 // through the shape-routed forms it is meant to cover
-enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_K2 = 6, ROUTE_N = 8 };
+enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_K2 = 6, ROUTE_R3 = 7, ROUTE_N = 8 };
 static long long g_route[ROUTE_N];
 #define ROUTE(k) __atomic_fetch_add(&g_route[k], 1LL, __ATOMIC_RELAXED)
 
@@ -1156,8 +1205,107 @@ static bool gemm8_wanted(const mofo_gemm_args* a, int count) {
     return a[0].op == MOFO_GEMM_NT && t256 >= 160 && (K >= 1024 || (K >= 512 && t256 >= 2000));
 }
 
+
+// ---- the 256 x 128 ring kernel (gemm_r3.h): host side.  Built for the weight gradients (TN, f32 out; split-K / accumulate with f32
+// atomics; fused bias-gradient column sums).  MOFO_GEMM_R3 = 0: never, 1: wherever legal, unset: by shape (r3_wanted).
+static bool r3_legal(const mofo_gemm_args* a, int count) {
+    if (count < 1 || count > MAXR) return false;
+    for (int i = 0; i < count; ++i)
+        if (a[i].op != MOFO_GEMM_TN || a[i].epilogue != MOFO_EPI_F32 || a[i].bias) return false;
+    return true;
+}
+// Grouped weight gradients whose 256 x 128 tiles give the 256 CUs at least about one round of deep reductions.  From the same-process
+// A/B at the step's shapes (tools/gemm_r3_ab.py, profiles/r05_gemm_r3_ab.txt).
+static bool r3_wanted(const mofo_gemm_args* a, int count) {
+    long long units = 0;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].M % R3_TM || a[i].N % R3_TN) return false;          // whole tiles only (the decoder's 384-wide outputs pad 256-row tiles by 14 %)
+        units += (long long)(a[i].M / R3_TM) * (a[i].N / R3_TN) * (a[i].splits < 1 ? 1 : a[i].splits);
+    }
+    return units >= 200 && a[0].K >= 2048;
+}
+static int r3_mode() {
+    const char* e = getenv("MOFO_GEMM_R3");      // read per call: A/B switches inside one process
+    return e ? atoi(e) : -1;
+}
+static int r3_fill(const mofo_gemm_args* a, int count, R3Group& g) {
+    g.count = count;
+    g.start[0] = 0;
+    for (int i = 0; i < count; ++i) {
+        GemmP full;
+        int blocks = 0;
+        const int rc = fill_problem(&a[i], full, R3_TM, R3_TN, blocks);
+        if (rc) return rc;
+        R3Prob& p = g.p[i];
+        p.A = full.A; p.B = full.B; p.C = full.C; p.colsum = full.colsum;
+        p.M = full.M; p.N = full.N; p.K = full.K; p.lda = full.lda; p.ldb = full.ldb; p.ldc = full.ldc;
+        p.k_per_split = full.k_per_split; p.atomic = full.atomic; p.skip_lo = full.colsum_skip_lo; p.skip_hi = full.colsum_skip_hi;
+        g.start[i + 1] = g.start[i] + blocks;
+    }
+    for (int i = count; i < MAXR; ++i) {
+        g.p[i] = g.p[0];
+        g.start[i + 1] = g.start[count];
+    }
+    const char* e = getenv("MOFO_GEMM_R3_TAIL");
+    g.tail = e ? atoi(e) : 1;
+    return MOFO_OK;
+}
+static int r3_grid() {
+    const char* e = getenv("MOFO_GEMM_R3_GRID");     // blocks (a multiple of 8; tests force a few so that every block walks several units)
+    int nb = e && atoi(e) > 0 ? atoi(e) : 256;
+    nb = (nb + 7) / 8 * 8;
+    return nb;
+}
+// which problems of the launch receive f32 atomics from SEVERAL blocks (units of a run's tail, or split / accumulating problems):
+// the caller zeroes those destinations (or accumulates on purpose).  Conservative: every problem that owns a tail unit is flagged.
+static void r3_plan(const R3Group& g, int nb, int* shared) {
+    const int total = g.start[g.count], nbx = nb >> 3;
+    for (int i = 0; i < g.count; ++i) shared[i] = g.p[i].atomic ? 1 : 0;
+    if (!g.tail) return;
+    const int q = total >> 3, r = total & 7;
+    for (int xcd = 0; xcd < 8; ++xcd) {
+        const int xbeg = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+        const int xlen = q + (xcd < r ? 1 : 0);
+        for (int u = (xlen / nbx) * nbx; u < xlen; ++u) {
+            int gi = 0;
+            for (int k = 1; k < g.count; ++k)
+                if (xbeg + u >= g.start[k]) gi = k;
+            shared[gi] = 1;
+        }
+    }
+}
+static int r3_launch(const mofo_gemm_args* a, int count, hipStream_t s) {
+    R3Group g;
+    const int rc = r3_fill(a, count, g);
+    if (rc) return rc;
+    const int total = g.start[count];
+    hipLaunchKernelGGL((gemm_r3_kernel<OPL_COL, OPL_COL, MOFO_EPI_F32>), dim3(r3_grid()), dim3(512), 0, s, g, total);
+    ROUTE(ROUTE_R3);
+    MOFO_CHECK_LAUNCH("mofo_gemm(r3)");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_gemm_grouped_plan(const mofo_gemm_args* a, int count, int* shared) {
+    if (!a || !shared || count < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped_plan: null argument");
+    const int mode = r3_mode();
+    if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count))) {
+        R3Group g;
+        const int rc = r3_fill(a, count, g);
+        if (rc) return rc;
+        r3_plan(g, r3_grid(), shared);
+        return 1;
+    }
+    for (int i = 0; i < count; ++i) shared[i] = (a[i].splits > 1 || a[i].accumulate) ? 1 : 0;
+    return 0;
+}
+
 extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* stream) {
-    if (!a || count < 1 || count > MAXG) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d", MAXG);
+    if (!a || count < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d", MAXG);
+    {
+        const int mode = r3_mode();
+        if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count))) return r3_launch(a, count, (hipStream_t)stream);
+    }
+    if (count > MAXG) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d (1..%d for weight-gradient groups on the 256 x 128 ring kernel)", MAXG, MAXR);
     GroupP g;
     g.count = count;
     g.start[0] = 0;

@@ -73,7 +73,11 @@ __device__ __forceinline__ void g8_stage_half(__amdgpu_buffer_rsrc_t r, int v, i
         } else {
             soff = ((unsigned)(k0 + 4 * i) * (unsigned)ld + (unsigned)(d0 + (IS_A ? h * 64 : h * 32))) * 2u;
         }
+#if MOFO_DMA_ASM_G8
+        lds_dma16<false>(r, dst + i * 1024, v, soff);       // inline asm: see lds_dma16 in gemm.hip
+#else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(r, LDS_PTR(dst + i * 1024), 16, v, (int)soff, 0, 0);
+#endif
     }
 }
 

@@ -65,8 +65,8 @@ __global__ __launch_bounds__(512, 2) void gemm_k2_kernel(GemmP p, int total) {
         const int k0 = kof(t);
         if (k0 >= p.K) return false;
         unsigned char* dst = gs + buf * STG;
-        stage_tile_srd<LA, MI>(ra, va0, va1, p.lda, m0, k0, dst, w4_u);
-        stage_tile_srd<LB, 4>(rb, vb0, vb1, p.ldb, n0, k0, dst + A_BYTES, w4_u);
+        stage_tile_srd<LA, MI, 0, MOFO_DMA_ASM_K2 != 0>(ra, va0, va1, p.lda, m0, k0, dst, w4_u);    // builtin pieces: see lds_dma16 in gemm.hip
+        stage_tile_srd<LB, 4, 0, MOFO_DMA_ASM_K2 != 0>(rb, vb0, vb1, p.ldb, n0, k0, dst + A_BYTES, w4_u);
         return true;
     };
     f32x4 acc[MI][4];

@@ -124,10 +124,23 @@ def gemm(op, epi, A, B, C_, **kw):
 
 
 def gemm_grouped(op, epi, problems):
-    """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 13)"""
+    """several GEMMs of one (op, epilogue) kind in ONE launch; ``problems`` = [(A, B, C, kwargs), ...] (at most 13; 32 for
+    weight-gradient groups, TN + F32)"""
     built = [_gemm_args(op, epi, A, B, C_, **kw) for A, B, C_, kw in problems]
     arr = (GemmArgs * len(built))(*[b[0] for b in built])
     _run("mofo_gemm_grouped", ("gemm", op, epi), (sum(b[1] for b in built), sum(b[2] for b in built)), arr, len(built))
+
+
+def gemm_grouped_plan(op, epi, problems):
+    """host-only: (routed to the 256 x 128 ring kernel?, per problem: may its C receive f32 atomic adds from several workgroups?) --
+    the caller zeroes those destinations before the launch (include/mofo_hip.h: mofo_gemm_grouped_plan)"""
+    built = [_gemm_args(op, epi, A, B, C_, **kw) for A, B, C_, kw in problems]
+    arr = (GemmArgs * len(built))(*[b[0] for b in built])
+    shared = (C.c_int * len(built))()
+    rc = _lib.load().mofo_gemm_grouped_plan(arr, len(built), shared)
+    if rc < 0:
+        _lib.check(rc, "mofo_gemm_grouped_plan")
+    return rc == 1, [bool(x) for x in shared]
 
 
 def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
@@ -203,7 +216,7 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
     return a, 2.0 * M * N * K, nbytes
 
 
-GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8", "k2")
+GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8", "k2", "r3")
 
 
 def gemm_route_counts(reset=False):

@@ -398,6 +398,73 @@ def test_gemm_k2_one_tile_per_cu_family(dev, monkeypatch, M, N, K, stag):
         assert torch.equal(Cb, first)
 
 
+@pytest.mark.parametrize("grid,tail", [("16", "1"), ("256", "1"), ("24", "0")])
+@pytest.mark.parametrize("R,P,Q", [(192, 256, 128), (320, 768, 384), (1000, 520, 264), (2888, 512, 256), (4096, 2304, 768), (40, 64, 128)])
+def test_gemm_r3_ring_family(dev, monkeypatch, R, P, Q, grid, tail):
+    """The 256 x 128 three-stage ring kernel (csrc/gemm_r3.h: counted vmcnt, fragments read one k-substep ahead, one barrier per
+    k-step), forced with MOFO_GEMM_R3=1 on a weight-gradient (TN, f32) problem: whole and ragged tiles, reductions that are not a
+    multiple of 64, split-K, the fused bias-gradient column sums, a grouped launch with different reduction lengths.  Grid 16 makes
+    every block walk several units AND share the last one of its run (rounds + tail chunks); grid 256 deals everything as tail
+    chunks (more blocks than units); tail = 0 is the plain round-by-round form.  Element-wise against fp32 torch on the same
+    bf16 operands, so that a stage read before its LDS-DMA landed (a race a norm would average away) shows; destinations the
+    plan does not flag as shared are poisoned with NaN first (every element must be stored), flagged ones are zeroed (atomics)."""
+    from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM_R3", "1")
+    monkeypatch.setenv("MOFO_GEMM_R3_GRID", grid)
+    monkeypatch.setenv("MOFO_GEMM_R3_TAIL", tail)
+
+    def close(C, want, tol=2e-3):
+        bad = ((C.float() - want).abs() > tol * want.abs().max()).sum().item()
+        assert bad == 0, f"{bad} elements off"
+        assert _rel(C, want) < 1e-5
+
+    def run(problems):
+        used, shared = ops.gemm_grouped_plan(ops.GEMM_TN, ops.EPI_F32, problems)
+        assert used
+        for (_, _, G, kw), sh in zip(problems, shared):
+            if kw.get("accumulate"):
+                continue
+            G.zero_() if sh else G.fill_(float("nan"))
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, problems)
+        return shared
+
+    dY, X = _rand((R, P), dev, 1, 0.1), _rand((R, Q), dev, 2, 0.1)
+    want = dY.float().t() @ X.float()
+    C = torch.empty(P, Q, dtype=F32, device=dev)
+    ops.gemm_route_counts(reset=True)
+    shared = run([(dY, X, C, dict(splits=1, accumulate=False))])
+    close(C, want)
+    if not shared[0]:       # one writer per element: repeated launches are bit-identical
+        first = C.clone()
+        for _ in range(10):
+            run([(dY, X, C, dict(splits=1, accumulate=False))])
+            assert torch.equal(C, first)
+    if R >= 256:
+        run([(dY, X, C, dict(splits=3, accumulate=False))])
+        close(C, want)
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, [(dY, X, C, dict(splits=2, accumulate=True))])
+        close(C, 2 * want)
+    # bias gradient riding on the weight gradient, with a skipped row range
+    bg = torch.full((P,), 0.5, dtype=F32, device=dev)
+    lo, hi = P // 3, 2 * P // 3
+    run([(dY, X, C, dict(splits=1, accumulate=False, colsum=bg, colsum_skip=(lo, hi)))])
+    close(C, want)
+    ref = dY.float().sum(0) + 0.5
+    ref[lo:hi] = 0.5
+    assert _rel(bg, ref) < 1e-5 and torch.all(bg[lo:hi] == 0.5)
+    # a grouped launch: five problems, three reduction lengths, whole and ragged shapes
+    shapes = [(P, Q, R), (384, 136, R), (256, 512, max(64, R - 72)), (264, 128, R), (768, 256, max(8, R // 2))]
+    probs, wants = [], []
+    for i, (p_, q_, r_) in enumerate(shapes):
+        a, b = _rand((r_, p_), dev, 20 + i, 0.1), _rand((r_, q_), dev, 30 + i, 0.1)
+        probs.append((a, b, torch.empty(p_, q_, dtype=F32, device=dev), dict(splits=1, accumulate=False)))
+        wants.append(a.float().t() @ b.float())
+    run(probs)
+    for (_, _, G, _), w in zip(probs, wants):
+        close(G, w)
+    assert ops.gemm_route_counts()["r3"] >= 3 and ops.gemm_route_counts()["tile"] == 0
+
+
 @pytest.mark.parametrize("Bc,n_all,skip,N,K", [(3, 40, 16, 192, 128), (2, 1568, 160, 384, 384), (4, 300, 44, 768, 1536), (32, 160, 24, 128, 64)])
 def test_gemm_residual_row_map(dev, Bc, n_all, skip, N, K):
     """RESID_F32 / RESID_BF16 with a residual ROW MAP (rows_in > 0): the output is dense over the n_all - skip kept rows of each of
