@@ -371,7 +371,26 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
 #ifndef MOFO_GEMM_NT_H1
 #define MOFO_GEMM_NT_H1 1
 #endif
-                if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_NT_H1) {
+#ifndef MOFO_ABL_NO_H1      // timing-only ablation builds (tools/gemm_epi_libs.py): drop the pre-activation / the activation store
+#define MOFO_ABL_NO_H1 0
+#endif
+#ifndef MOFO_ABL_NO_G
+#define MOFO_ABL_NO_G 0
+#endif
+#ifndef MOFO_GEMM_NT_G
+#define MOFO_GEMM_NT_G 0
+#endif
+#ifndef MOFO_GEMM_SC1_H1     // experiment: write-through stores that do not stay in the XCD's L2 (MI355X_MICROARCH.md: plain / nt stores keep the line)
+#define MOFO_GEMM_SC1_H1 0
+#endif
+#ifndef MOFO_GEMM_SC1_G
+#define MOFO_GEMM_SC1_G 0
+#endif
+                if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_ABL_NO_H1) {
+                    asm volatile("" ::"v"(o));
+                } else if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_SC1_H1) {
+                    if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((bf16_t*)p.C + (size_t)m * p.ldc + n), "v"(o) : "memory");
+                } else if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_NT_H1) {
                     // the pre-activation is not read again before the backward pass: stored non-temporally, it leaves the Infinity
                     // Cache to the activation (C2) that the next GEMM reads (308 MB of outputs per decoder fc1 for 256 MB of cache)
                     if (ok) __builtin_nontemporal_store(o, (u32x4*)((bf16_t*)p.C + (size_t)m * p.ldc + n));
@@ -382,7 +401,10 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                     const f32x2 g0 = gelu_erf2((f32x2){v0[0], v0[1]}), g1 = gelu_erf2((f32x2){v0[2], v0[3]});
                     const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
                     const u32x4 gg = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
-                    if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = gg;
+                    if constexpr (MOFO_ABL_NO_G) asm volatile("" ::"v"(gg));
+                    else if constexpr (MOFO_GEMM_SC1_G) { if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n), "v"(gg) : "memory"); }
+                    else if constexpr (MOFO_GEMM_NT_G) { if (ok) __builtin_nontemporal_store(gg, (u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n)); }
+                    else if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = gg;
                 }
             }
             __builtin_amdgcn_wave_barrier();
@@ -641,6 +663,24 @@ __global__ __launch_bounds__(256, (VAR == 1 ? 3 : 2)) void gemm_kernel(GroupP G)
 #endif
 }
 
+// s_waitcnt with only the vector-memory counter set (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0], expcnt imm[6:4], lgkmcnt imm[11:8])
+#define G8_WAIT_VM(n)                                                                      \
+    do {                                                                                   \
+        __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))); \
+        asm volatile("" ::: "memory");                                                     \
+    } while (0)
+
+// Vector-memory STORES a wave issues in the epilogue of one FULL (16 MI) x 64 wave tile (epilogue<> above, branch-free path): the bf16
+// forms write 8 rows x 128 B per instruction (BIAS_GELU: two outputs), the f32 forms 4 rows x 256 B; loads of the epilogue (bias,
+// residual, pre-activation rows) are consumed before its last store is issued and do not stay in the queue.  POS_* also gather
+// index / table rows per group (not counted: S must not exceed the truth).
+template <int EPI, int MI>
+constexpr int pers_epi_stores() {
+    return EPI == MOFO_EPI_BIAS_GELU ? 4 * MI
+         : (EPI == MOFO_EPI_BF16 || EPI == MOFO_EPI_DGELU_BF16 || EPI == MOFO_EPI_RESID_BF16) ? 2 * MI
+         : 4 * MI;   // F32, RESID_F32, POS_*: (16 MI / 4) row groups
+}
+
 // VAR 2: PERSISTENT form of VAR 1 for the single-problem NT / NN GEMMs (no split-K).  Phase stamps of VAR 1 at the decoder
 // shapes (K = 384: six k-iterations per tile) showed 13-18 % of a block's life spent waiting for its FIRST operand tile
 // (kernel-argument fetch + LDS-DMA issue + HBM/L2 latency) with nothing else to do.  Here at most 3 x 256 blocks are
@@ -696,6 +736,7 @@ __global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(G
     int w = blockIdx.x, m0, n0;
     decode(w, m0, n0);
     stage(m0, n0, 0);
+    bool prev_full = false;     // the previous tile took the branch-free epilogue: its store count is known
     for (;;) {
         const int wnext = w + (int)gridDim.x;
         const bool has_next = wnext < total;
@@ -707,7 +748,18 @@ __global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(G
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ti == 2) MOFO_TRACE(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this tile's first k-stage (and the previous epilogue's stores)
+        // This tile's first k-stage was issued BEFORE the previous tile's epilogue, i.e. it is OLDER than that epilogue's stores in the
+        // wave's in-order vmcnt queue: `vmcnt(S)` with S = the stores that epilogue issued waits for the stage alone and leaves the
+        // stores one more k-step to be acknowledged (the wait at the end of k-step 0 covers them).  Ablation (profiles/r05_epi_ablate.txt):
+        // the decoder's fc1 + GELU takes 98 us with and 78 us without its stores although they need 45 us of HBM time -- each tile paid
+        // ~3 us here waiting for acknowledges.  S is exact for full tiles (a LOWER bound is all the wait needs: a smaller count only
+        // waits for more); after a ragged tile (stores branched around) and for the first tile the wait is vmcnt(0).
+#ifndef MOFO_PERSIST_COUNTED
+#define MOFO_PERSIST_COUNTED 1
+#endif
+        constexpr int SE = pers_epi_stores<EPI, MI>();
+        if (MOFO_PERSIST_COUNTED && LB == OPL_ROW && prev_full) G8_WAIT_VM(SE);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (ti == 2) MOFO_TRACE(1);
         for (int t = 0; t < nk; ++t) {
@@ -736,7 +788,8 @@ __global__ __launch_bounds__(256, MI == 8 ? 2 : 3) void gemm_persistent_kernel(G
             }
         }
         if (ti == 2) MOFO_TRACE(2);
-        epilogue<EPI, MI, MI>(p, acc, ep, m0 + wm * (16 * MI), n0 + wn * 64, (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, ti == 2);
+        prev_full = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
+        epilogue<EPI, MI, MI>(p, acc, ep, m0 + wm * (16 * MI), n0 + wn * 64, prev_full, lane, ti == 2);
         if (ti == 2) {
             MOFO_TRACE(4);
             MOFO_TRACE(5);
@@ -1214,15 +1267,37 @@ static bool r3_legal(const mofo_gemm_args* a, int count) {
         if (a[i].op != MOFO_GEMM_TN || a[i].epilogue != MOFO_EPI_F32 || a[i].bias) return false;
     return true;
 }
-// Grouped weight gradients whose 256 x 128 tiles give the 256 CUs at least about one round of deep reductions.  From the same-process
-// A/B at the step's shapes (tools/gemm_r3_ab.py, profiles/r05_gemm_r3_ab.txt).
-static bool r3_wanted(const mofo_gemm_args* a, int count) {
+// Which weight-gradient groups go to the ring kernel by default, from the same-process A/B at the step's shapes (tools/gemm_r3_ab.py,
+// profiles/r05_gemm_r3_ab.txt).  While all 256 CUs hold a unit the ring kernel and the 128 x 128 kernel (three blocks per CU) run at
+// the same rate on the encoder's shapes (1 157 vs 1 135 TFLOP/s: both sit on the CU's fill path), so the
+// choice is a question of ROUNDS: 216 units per encoder block on 256 slots against 432 tiles on 768.
+//   1 block 0.84 rounds: 0.94-0.98 x | 2 blocks 1.69: 1.12-1.22 x | 3 blocks 2.53: 0.94-0.97 x | 6 blocks 5.06 with the tail dealt in
+//   chunks: 1.02 x | 7 blocks 5.91: 1.04 x (the 128 x 128 kernel takes at most three blocks per launch)
+// Whole tiles only: the decoder's 384-wide outputs pad 256-row tiles by 14 % (0.65-0.92 x, not routed).
+static bool r3_rounds(const mofo_gemm_args* a, int count, double* rounds) {
     long long units = 0;
     for (int i = 0; i < count; ++i) {
-        if (a[i].M % R3_TM || a[i].N % R3_TN) return false;          // whole tiles only (the decoder's 384-wide outputs pad 256-row tiles by 14 %)
+        if (a[i].M % R3_TM || a[i].N % R3_TN || a[i].K < 2048) return false;
         units += (long long)(a[i].M / R3_TM) * (a[i].N / R3_TN) * (a[i].splits < 1 ? 1 : a[i].splits);
     }
-    return units >= 200 && a[0].K >= 2048;
+    *rounds = (double)units / 256.0;
+    return true;
+}
+static bool r3_wanted(const mofo_gemm_args* a, int count) {
+    double r;
+    if (!r3_rounds(a, count, &r)) return false;
+    const int fl = (int)r;
+    const double frac = r - fl;
+    if (fl >= 4) return true;                                 // many rounds: at most one in five is partly filled, or its units are dealt in chunks
+    return fl >= 1 && (frac == 0.0 || frac >= 0.65);
+}
+// the last, partial round of a run is dealt in chunks (f32 atomics onto zeroed destinations) only when it is a small share of the
+// launch: every unit of it costs its sharers an atomic pass over its 128 KiB (1.3 TB/s chip-wide; 1 block: 0.52 x, 6 blocks: 1.02 x)
+static int r3_tail_auto(const mofo_gemm_args* a, int count) {
+    double r;
+    if (!r3_rounds(a, count, &r)) return 0;
+    const int fl = (int)r;
+    return fl >= 4 && r - fl > 0.0 && r - fl <= 0.2;
 }
 static int r3_mode() {
     const char* e = getenv("MOFO_GEMM_R3");      // read per call: A/B switches inside one process
@@ -1246,8 +1321,8 @@ static int r3_fill(const mofo_gemm_args* a, int count, R3Group& g) {
         g.p[i] = g.p[0];
         g.start[i + 1] = g.start[count];
     }
-    const char* e = getenv("MOFO_GEMM_R3_TAIL");
-    g.tail = e ? atoi(e) : 1;
+    const char* e = getenv("MOFO_GEMM_R3_TAIL");     // 0 / 1 forces plain rounds / tail chunks (tests, A/B); unset: by shape
+    g.tail = e ? atoi(e) : r3_tail_auto(a, count);
     return MOFO_OK;
 }
 static int r3_grid() {

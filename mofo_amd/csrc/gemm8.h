@@ -81,13 +81,6 @@ __device__ __forceinline__ void g8_stage_half(__amdgpu_buffer_rsrc_t r, int v, i
     }
 }
 
-// s_waitcnt with only the vector-memory counter set (gfx9 encoding: vmcnt = imm[15:14]:imm[3:0], expcnt imm[6:4], lgkmcnt imm[11:8])
-#define G8_WAIT_VM(n)                                                                      \
-    do {                                                                                   \
-        __builtin_amdgcn_s_waitcnt((((n) & 15) | (7 << 4) | (15 << 8) | (((n) >> 4) << 14))); \
-        asm volatile("" ::: "memory");                                                     \
-    } while (0)
-
 // A LOWER bound on the vector-memory operations (loads AND stores: one in-order counter) a wave issues in the epilogue of one FULL
 // 128 x 64 wave tile -- the vmcnt budget of the first K-tile after it: `vmcnt(8 + S)` retires the prefetched pieces that sit BEHIND
 // the epilogue's S operations in the counter only if the wave really issued >= S of them.  A larger S waits for LESS, so S must never

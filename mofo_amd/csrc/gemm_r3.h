@@ -27,12 +27,6 @@
 // zeroed -- mofo_gemm_grouped_plan says which problems that concerns).  432 / 864 / 1296 / 2592 tiles of a 1 / 2 / 3 / 6-block
 // encoder group are 0.84 / 1.69 / 2.53 / 5.06 rounds of 256: without the tail split every launch would run at 84 % fill.
 
-#ifndef R3_DEPHASE
-#define R3_DEPHASE 0
-#endif
-#ifndef R3_CHAIN
-#define R3_CHAIN 0
-#endif
 #ifndef R3_NO_DMA
 #define R3_NO_DMA 0
 #endif
@@ -244,26 +238,21 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
         }
     };
 
-    R3Seg cs, ns;
-    if (!next_seg(cs)) return;
-    bool pend16 = false;                           // the segment before left exactly 16 result stores in this wave's vmcnt queue
-    Ctx cur = make_ctx(cs);
-    int bt = 0;                                    // ring buffer of the current stage t
-    bool fresh = true;                             // the stream is (re)started for cs: nothing of it is in flight yet
-    for (;;) {
-        const bool has_next = next_seg(ns);
-        const Ctx nxt = make_ctx(has_next ? ns : cs);
-        // THE STREAM RUNS ON INTO THE NEXT SEGMENT: the pieces a step issues for stages nk, nk + 1, nk + 2 are stages 0, 1, 2 of the next
-        // segment, its first fragments are read by the last half-step of this one, and the results of this one leave straight from the
-        // accumulators (no LDS staging: the ring is never idle) while the next main loop is already running.  Segments of fewer
-        // than three k-steps (test geometries) do not chain: the stream is drained and restarted around them (their stages past the
-        // end are dropped by the range check).
-        const bool chain = R3_CHAIN && has_next && cs.nk >= 3 && ns.nk >= 3;
+    // TRIED AND NOT KEPT (commit cf2a863 has the code; profiles/r05_gemm_r3_ab.txt the numbers):
+    //  * the stream running on into the next segment (its stages 0-2 issued from this one's last steps, results stored straight from
+    //    the accumulators because the ring is never idle): 0.96-0.98 x -- fragment-layout stores are 64-B segments, they hold the
+    //    in-order vmcnt queue longer than the drain they save, and f32 atomics in 64-B segments run at a fraction of the 256-B-row rate;
+    //  * de-phasing the two waves of a SIMD (bursts after MFMAs 2, 6, 10, 14 of a half for waves 4-7): 0.95 x;
+    //  * pieces issued together behind the barrier, reads spread one pair per MFMA group: 0.96 x; no s_setprio, no sched_group_barrier: +-1 %.
+    R3Seg cs;
+    while (next_seg(cs)) {
+        const Ctx cur = make_ctx(cs);
         const int nk = cs.nk;
         const R3Prob& p = G.p[cs.gi];
         const bool do_colsum = CAN_COLSUM && p.colsum != nullptr && cs.n0 == 0 && wn == 0;
+        int bt = 0;                                // ring buffer of the current stage t
         zero_acc();
-        if (fresh) {
+        {
             // ---- prologue: stages 0, 1 and the A pieces of stage 2 in flight; ks = 0 fragments of step 0 on their way to registers
             pieces_a(cur, 0, 0);
             pieces_b(cur, 0, 0);
@@ -282,18 +271,16 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
                 fb[1][i] = read_b(smem, i, 1);
 #endif
             }
-            bt = 0;
         }
-        // 16 (20) MFMAs of one k-substep from set KS with four BURSTS of other work between them: burst 0 = the B fragment reads of the
-        // OTHER set from `src` (8 ds_read_b64_tr_b16), burst 1 = its A fragment reads, bursts 2, 3 = the LDS-DMA pieces `dma(2 / 3)`.
-        // Ablation builds (profiles/r05_gemm_r3_ablate.txt) showed the cost of a k-step to be the SUM of its parts -- 0.45 us of MFMAs +
-        // 0.17 of fragment reads + 0.27 of piece issue = 0.93: a wave issues in order, and while it issues reads or pieces (60-185 clk
-        // per piece, MI355X_MICROARCH.md) it issues no MFMA; the partner wave of its SIMD (wave w + 4) could, but ran the same program in
-        // lock-step from the same barrier and reached its own burst at the same moment.  PH de-phases the partners: waves 0-3 place the
-        // bursts after MFMAs 4, 8, 12, 16 of the half, waves 4-7 (PH = 2) after MFMAs 2, 6, 10, 14 -- one wave's burst now falls into the
-        // middle of the other's MFMA group.
-        auto half = [&](auto ks_tag, auto cs_tag, auto ph_tag, const unsigned char* src, auto dma) {
-            constexpr int KS = decltype(ks_tag)::value, PH = decltype(ph_tag)::value;
+        // 16 (20) MFMAs of one k-substep from set KS with four BURSTS of other work behind MFMAs 4, 8, 12, 16: burst 0 = the B fragment
+        // reads of the OTHER set from `src` (8 ds_read_b64_tr_b16), burst 1 = its A fragment reads, bursts 2, 3 = the LDS-DMA pieces
+        // `dma(2 / 3)` -- the issue cost of a piece (60-185 clk of the wave's instruction stream, MI355X_MICROARCH.md) stays out of the
+        // head of the half.  Ablation builds (profiles/r05_gemm_r3_ablate.txt) show the cost of a k-step to be close to the SUM of its
+        // parts -- 0.45 us of MFMAs + 0.17 of fragment reads + 0.27 of piece issue against 0.93 measured: a wave issues in order, and
+        // while it issues reads or pieces it issues no MFMA.
+        auto half = [&](auto ks_tag, auto cs_tag, const unsigned char* src, auto dma) {
+            constexpr int KS = decltype(ks_tag)::value;
+            constexpr int PH = 0;
             constexpr bool CS = decltype(cs_tag)::value;
             auto burst = [&](int b) {
 #if !R3_NO_READ
@@ -330,53 +317,38 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
             __builtin_amdgcn_s_setprio(0);
 #endif
         };
-        // one k-step.  Pieces: B of stage t + 2 in half (t, 0), A of stage t + 3 in half (t, 1) -- of the next segment once past nk.
-        // W = the younger vector-memory operations allowed to stay in flight at B_t: stage t + 1's last pieces (its B pieces, issued in
-        // half (t - 1, 0)) have A(t + 2) and B(t + 2) behind them = 6, plus, in the first step of a chained segment, the stores of
-        // the segment before (a LOWER bound of their count: a smaller W only waits for more).
-        auto step = [&](auto cs_tag, auto ph_tag, auto w_tag, int t) {
-            constexpr int W = decltype(w_tag)::value;
+        // one k-step.  Pieces: B of stage t + 2 in half (t, 0), A of stage t + 3 in half (t, 1).  Stages past the segment's last k-step are
+        // issued all the same (ONE straight-line loop body: no tail variants, the accumulators stay in place): past the unit's reduction
+        // range the hardware range check drops them, inside it (a tail chunk that ends before its unit does) they fetch three stages
+        // nobody multiplies.
+        // vmcnt at B_t: stage t + 1's last pieces (its B pieces, issued in half (t - 1, 0)) have A(t + 2) and B(t + 2) behind them = 6.
+        auto step = [&](auto cs_tag, int t) {
             const int bn = bt == 2 ? 0 : bt + 1;   // buffer of stage t + 1
             const int bp = bt == 0 ? 2 : bt - 1;   // buffer of stage t + 2 (= of stage t - 1)
-            const bool o2 = chain && t + 2 >= nk, o3 = chain && t + 3 >= nk;
-            const Ctx& c2 = o2 ? nxt : cur;
-            const Ctx& c3 = o3 ? nxt : cur;
-            const int t2 = o2 ? t + 2 - nk : t + 2, t3 = o3 ? t + 3 - nk : t + 3;
-            half(std::integral_constant<int, 0>{}, cs_tag, ph_tag, smem + bt * R3_STG, [&](int g) {
-                if (g == 2) piece(std::integral_constant<int, 4>{}, c2, t2, bp);
-                else piece(std::integral_constant<int, 5>{}, c2, t2, bp);
+            half(std::integral_constant<int, 0>{}, cs_tag, smem + bt * R3_STG, [&](int g) {
+                if (g == 2) piece(std::integral_constant<int, 4>{}, cur, t + 2, bp);
+                else piece(std::integral_constant<int, 5>{}, cur, t + 2, bp);
             });
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // set 1 is in registers: this wave has read all of stage t
-            G8_WAIT_VM(W);                         // stage t + 1 landed (this wave's pieces)
+            G8_WAIT_VM(6);                         // stage t + 1 landed (this wave's pieces); six younger pieces keep flying
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_barrier();          // B_t: stage t + 1 is visible to every wave, the buffer of stage t is free
             __builtin_amdgcn_sched_barrier(0);
-            half(std::integral_constant<int, 1>{}, cs_tag, ph_tag, smem + bn * R3_STG, [&](int g) {
+            half(std::integral_constant<int, 1>{}, cs_tag, smem + bn * R3_STG, [&](int g) {
                 if (g == 2) {
-                    piece(std::integral_constant<int, 0>{}, c3, t3, bt);
-                    piece(std::integral_constant<int, 1>{}, c3, t3, bt);
+                    piece(std::integral_constant<int, 0>{}, cur, t + 3, bt);
+                    piece(std::integral_constant<int, 1>{}, cur, t + 3, bt);
                 } else {
-                    piece(std::integral_constant<int, 2>{}, c3, t3, bt);
-                    piece(std::integral_constant<int, 3>{}, c3, t3, bt);
+                    piece(std::integral_constant<int, 2>{}, cur, t + 3, bt);
+                    piece(std::integral_constant<int, 3>{}, cur, t + 3, bt);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
             bt = bn;
         };
-        auto loop = [&](auto cs_tag, auto ph_tag) {
-            // the first step of a chained segment: the stores of the segment before sit between B(1) and A(2) .. in the in-order counter
-            if (pend16) step(cs_tag, ph_tag, std::integral_constant<int, 22>{}, 0);
-            else step(cs_tag, ph_tag, std::integral_constant<int, 6>{}, 0);
-            for (int t = 1; t < nk; ++t) step(cs_tag, ph_tag, std::integral_constant<int, 6>{}, t);
-        };
         auto loops = [&](auto cs_tag) {
-#if R3_DEPHASE
-            if (wave >= 4) loop(cs_tag, std::integral_constant<int, 2>{});
-            else loop(cs_tag, std::integral_constant<int, 0>{});
-#else
-            loop(cs_tag, std::integral_constant<int, 0>{});
-#endif
+            for (int t = 0; t < nk; ++t) step(cs_tag, t);
         };
         if constexpr (CAN_COLSUM) {
             if (do_colsum) loops(std::true_type{});
@@ -384,13 +356,11 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
         } else {
             loops(std::false_type{});
         }
-        if (!chain) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the look-ahead reads of the step after the last one
-            G8_WAIT_VM(0);                         // ... and the stages issued past the end have landed (or were dropped)
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_barrier();          // nobody restarts the ring while another wave's pieces are still landing in it
-            __builtin_amdgcn_sched_barrier(0);
-        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the look-ahead reads of the step after the last one
+        G8_WAIT_VM(0);                             // ... and the stages issued past the end have landed (or were dropped)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();              // every wave is done with the ring: it becomes the epilogue's staging area
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (CAN_COLSUM) {
             if (do_colsum && lane < 16) {          // D[n][m]: every row n holds the same sum; lanes 0..15 hold m = 16 i + lane in element 0
 #pragma unroll
@@ -401,36 +371,6 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
             }
         }
         const bool full = (cs.m0 + R3_TM <= p.M) && (cs.n0 + R3_TN <= p.N);
-#if R3_CHAIN
-        // ---- results straight from the accumulators (the ring is never idle when segments chain): acc[i][j][e] = C[m0 + 64 wm + 16 i + (lane & 15)][n0 + 64 wn + 16 j + 4 (lane >> 4) + e],
-        // 16 rows x 64 B per store instruction.  MEASURED SLOWER than the staged form below (profiles/r05_gemm_r3_ab.txt): 64-B segments hold
-        // the in-order vmcnt queue longer than the drain they save, and f32 atomics in 64-B segments run at a fraction of the 256-B-row rate.
-        {
-            float* Cf = (float*)p.C;
-            const int mr = cs.m0 + wm * 64 + (lane & 15), nc = cs.n0 + wn * 64 + 4 * (lane >> 4);
-            if (cs.atomic) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mr + 16 * i, n = nc + 16 * j;
-                        if (m < p.M && n < p.N) {
-                            float* d = Cf + (size_t)m * p.ldc + n;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) atomicAdd(d + e, acc[i][j][e]);
-                        }
-                    }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int m = mr + 16 * i, n = nc + 16 * j;
-                        if (full || (m < p.M && n < p.N)) *(f32x4*)(Cf + (size_t)m * p.ldc + n) = acc[i][j];
-                    }
-            }
-        }
-#else
         // ---- results through the (drained) ring: the shared epilogue stages the wave's 64 x 64 f32 tile in LDS and leaves in whole
         // 256-B row segments (plain stores, or one 256-B row per f32 atomic instruction for a shared / split / accumulating unit)
         {
@@ -445,11 +385,5 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
             __builtin_amdgcn_s_barrier();          // the staging area becomes the next segment's ring
             __builtin_amdgcn_sched_barrier(0);
         }
-#endif
-        if (!has_next) break;
-        pend16 = chain && full && !cs.atomic;      // exactly 16 stores were issued by this wave (a lower bound is all the wait needs)
-        fresh = !chain;
-        cs = ns;
-        cur = nxt;
     }
 }

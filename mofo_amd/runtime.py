@@ -268,7 +268,13 @@ def _wsplits(P, Q, R):
     return int(max(1, min(-(-256 // tiles), 16, R // 1024)))
 
 
-def _pick_wgrad_blocks(D: int, hid: int) -> int:
+def _pick_wgrad_blocks(D: int, hid: int, depth: int = 12, bucketed: bool = True) -> int:
+    """encoder blocks per grouped weight-gradient launch.  Two kernels take such a group (csrc/gemm.hip: r3_wanted): the 128 x 128 form
+    (768 resident tiles, at most three blocks = 13 problems per launch) and the 256 x 128 ring kernel (256 resident units, up to 7
+    blocks).  While every slot is filled both run at the same rate, so the group size is chosen for whole ROUNDS.  With gradient
+    buckets to hand over (data parallel) a group never spans a bucket end and the small late buckets decide: <= 3 as before.  In
+    one process the groups run on across the bucket ends: ViT-B 216 units per block -> 7 blocks = 5.9 rounds (then 5 + the patch embed =
+    4.4) against 3 blocks = 1.69 rounds of the 128 x 128 form."""
     t128 = lambda p, q: -(-p // 128) * -(-q // 128)
     t = t128(3 * D, D) + t128(D, D) + t128(hid, D) + t128(D, hid)      # 128 x 128 tiles of one block's four weight gradients
     best, best_eff = 1, 0.0
@@ -276,6 +282,12 @@ def _pick_wgrad_blocks(D: int, hid: int) -> int:
         eff = g * t / (-(-g * t // 768) * 768)
         if eff > best_eff + 1e-9:
             best, best_eff = g, eff
+    if not bucketed and D % 256 == 0 and hid % 256 == 0 and os.environ.get("MOFO_GEMM_R3", "") != "0":
+        u = (3 * D // 256) * (D // 128) + (D // 256) * (D // 128) + (hid // 256) * (D // 128) + (D // 256) * (hid // 128)
+        for g in range(4, min(7, depth) + 1):
+            eff = g * u / (-(-g * u // 256) * 256)
+            if g * u >= 4 * 256 and eff > best_eff + 0.03:
+                best, best_eff = g, eff
     return best
 
 
@@ -304,8 +316,11 @@ class PretrainRuntime:
         # encoder blocks per grouped weight-gradient launch: MOFO_WGRAD_BLOCKS, else the smallest group that fills whole rounds of the
         # 768 resident 128 x 128 tiles best (ViT-B: 432 tiles per block -> 3 blocks = 1.69 rounds; ViT-L: 768 per block -> 1 block = one
         # round exactly: 53.9 / 53.1 / 51.4 ms per step with 3 / 2 / 1 blocks per launch)
-        self.wgrad_blocks = max(1, min(3, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
-            _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio))
+        # (in one process -- no process group at construction -- nothing is handed over at bucket ends and the groups may be larger)
+        import torch.distributed as _td
+        bucketed = _td.is_available() and _td.is_initialized() and _td.get_world_size() > 1
+        self.wgrad_blocks = max(1, min(7, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
+            _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio), dims.enc_depth, bucketed)
         self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         # forward_only: the fine-tune / feature-extraction forward (modeling_finetune.py) -- no gradient buckets to plan
         self.segments = [] if forward_only else self.plan_segments()
@@ -630,21 +645,31 @@ class PretrainRuntime:
         # 108 tiles x 7: 242 -> 228 us) and 40 do not (encoder, 5 120 rows: 2.28 -> 2.68 ms per step when split).
         thr, target = int(os.environ.get("MOFO_WGRAD_THR", "600")), int(os.environ.get("MOFO_WGRAD_TARGET", "756"))
         splits = 1 if tiles >= thr else int(max(1, min(-(-target // tiles), 16, R // 4096)))
-        if splits == 1 and not self._accumulate and os.environ.get("MOFO_ZERO_ALL", "0") != "1":
-            for pr in problems:                # plain stores: zero_grad may skip these tensors from now on
-                self.store.mark_overwritten(pr[2])
-        elif splits > 1:
-            for pr in problems:                # f32 atomics onto what zero_grad left there
+        probs = [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip)) for dY, X, G, bg, skip in problems]
+        # which kernel takes the group, and which destinations receive f32 atomics from several workgroups (split reductions, or --
+        # ring kernel -- the units of a last, partial round dealt in chunks): those must hold zeros, the others are plainly stored
+        ring, shared = ops.gemm_grouped_plan(ops.GEMM_TN, ops.EPI_F32, probs)
+        if not ring and len(probs) > 13:
+            # the 128 x 128 kernel takes 13 problems (three blocks + one) per launch
+            chunks = [problems[i:i + 12] for i in range(0, len(problems), 12)]
+            if len(chunks) > 1 and len(chunks[-1]) == 1:
+                chunks[-2] += chunks.pop()
+            for c in chunks:
+                self._wgrad_group(c)
+            return
+        for pr, sh in zip(problems, shared):
+            if not sh and not self._accumulate and os.environ.get("MOFO_ZERO_ALL", "0") != "1":
+                self.store.mark_overwritten(pr[2])     # plain stores: zero_grad may skip this tensor from now on
+            elif sh:
+                # f32 atomics onto what zero_grad left there
                 if self.store.mark_accumulated(pr[2]) and not self._accumulate:
                     # (recording run only) another workspace's backward had made zero_grads skip this tensor.  The clear runs
-                    # on the stream the split-K launch below is issued on (the side stream inside _wgrad_flush), so that it is
+                    # on the stream the launch below is issued on (the side stream inside _wgrad_flush), so that it is
                     # ordered before that launch's atomics; a torch op on the CURRENT stream would race with them.
                     st = ops.launch_stream()
                     with torch.cuda.stream(st):
                         pr[2].zero_()
-        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32,
-                         [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip))
-                          for dY, X, G, bg, skip in problems])
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, probs)
 
     def _block_bwd(self, W, L, S, j, x_in, B, n, H, flush=False, hold=False, share=None):
         """Backward of the j-th block of a backward pass (j = 0 for the top block).  Reads the gradient wrt the block output

@@ -46,6 +46,8 @@ def launches(blocks, splits, per_launch):
 
 def arm(env, groups):
     def f():
+        for k in ("MOFO_GEMM_R3", "MOFO_GEMM_R3_TAIL"):
+            os.environ.pop(k, None)
         for k, v in env.items():
             os.environ[k] = v
         for probs in groups:
@@ -86,15 +88,18 @@ def check(blocks, splits):
 R3 = {"MOFO_GEMM_R3": "1", "MOFO_GEMM_R3_TAIL": "1"}
 R3N = {"MOFO_GEMM_R3": "1", "MOFO_GEMM_R3_TAIL": "0"}
 OLD = {"MOFO_GEMM_R3": "0"}
+AUTO = {}
 
 print("# tools/gemm_r3_ab.py: grouped weight gradients, us per group of blocks (median of %d interleaved rounds, steady state)" % ROUNDS)
 enc = [block(5120, 768, 3072, 100 + i) for i in range(7)]
 fl = 2.0 * 5120 * 768 * 768 * 12
 check(enc, 1)
-for nb in (1, 2, 3, 6, 7):
+for nb in (1, 2, 3, 5, 6, 7):
     arms = [("128 x 128 x3/CU (launches of <= 3 blocks)", OLD, launches(enc[:nb], 1, 3)),
             ("ring 256 x 128, tail chunks", R3, launches(enc[:nb], 1, nb)),
-            ("ring 256 x 128, plain rounds", R3N, launches(enc[:nb], 1, nb))]
+            ("ring 256 x 128, plain rounds", R3N, launches(enc[:nb], 1, nb)),
+            ("default routing (r3_wanted / r3_tail_auto), one group", AUTO, launches(enc[:nb], 1, nb) if nb <= 3 else None)]
+    arms = [a for a in arms if a[2] is not None]
     compare(f"ViT-B encoder, {nb} block(s): 5 120 token rows, D = 768", enc[:nb], fl * nb, arms)
 del enc
 torch.cuda.empty_cache()
