@@ -146,6 +146,12 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
+        rccl_log = None
+        if backend == "nccl" and world > 1 and "NCCL_DEBUG" not in os.environ:
+            # what RCCL built for this job (channels, rings / trees, transport): its INIT log goes to a per-rank file, rank 0 relays a
+            # digest to stderr below.  The first 8-GPU record then says how many CUs the exchange occupies beside the backward.
+            rccl_log = f"/tmp/mofo_rccl_{os.getpid()}.log"
+            os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT,GRAPH", NCCL_DEBUG_FILE=rccl_log)
         try:
             if backend == "nccl":
                 dist.init_process_group("nccl", init_method="env://", world_size=world, rank=rank, device_id=dev)
@@ -161,6 +167,15 @@ def main():
             os.close(saved_stdout)
         if rccl_ranks != dist.get_world_size() or rccl_ranks != world:
             raise SystemExit(f"collective backend '{backend}' sees {rccl_ranks} ranks, expected {world}")
+        if rccl_log and rank == 0:
+            try:
+                keep = [ln.strip() for ln in open(rccl_log, errors="replace")
+                        if any(k in ln for k in ("Channel", "channels", "Connected", "Trees", "Ring", "nranks", "comm 0x", "Using"))]
+                for ln in keep[:16]:
+                    print("[bench] rccl: " + ln[-220:], file=sys.stderr, flush=True)
+                print(f"[bench] rccl: {sum('Channel' in ln for ln in keep)} channel lines in the INIT log", file=sys.stderr, flush=True)
+            except OSError as exc:
+                print(f"[bench] rccl: no INIT log ({exc})", file=sys.stderr, flush=True)
     else:
         rccl_ranks = 1
 
@@ -249,7 +264,7 @@ def main():
             opt.zero_grad()
             loss_.backward()
         try:
-            ar_check = wrapped.sync.value_check(_bwd_only)
+            ar_check = wrapped.sync.value_check(_bwd_only, tol=2e-2 if os.environ.get("MOFO_GRAD_BF16") == "1" else 1e-4)
         except Exception as exc:      # the check must never take the scaling measurement down with it: report, go on timing
             ar_check = {"ok": False, "max_rel": float("nan"), "ranges": 0, "worst_range": None, "error": f"{type(exc).__name__}: {exc}"}
         opt.zero_grad()
@@ -257,6 +272,49 @@ def main():
             print(f"[bench] all-reduce value check: {'ok' if ar_check['ok'] else 'FAIL'} (max relative error {ar_check['max_rel']:.2e} over "
                   f"{ar_check['ranges']} ranges, worst {ar_check['worst_range']}{', ' + ar_check['error'] if 'error' in ar_check else ''})",
                   file=sys.stderr, flush=True)
+    # Route A/B under the LIVE exchange (first multi-GPU runs: nothing below was ever measured beside an N-rank RCCL all-reduce, whose
+    # channel workgroups stay resident on tens of CUs for most of the backward).  Two choices assume they own every CU: the
+    # one-128x128-tile-per-CU GEMM (gemm_k2: 240 blocks x 128 KiB of LDS; MOFO_GEMM_K2=0 routes its shapes back to the co-resident
+    # forms) and the weight-gradient launches on the main stream (MOFO_WGRAD_STREAM=side moves them beside the chain).  Five untimed
+    # steps of each of the four combinations, max over ranks, the fastest is kept for the timed region; all four are reported.
+    dp_ab = None
+    if (world > 1 or force_dp) and os.environ.get("MOFO_DP_ROUTE_AB", "1") == "1":
+        user = {k: os.environ.get(k) for k in ("MOFO_GEMM_K2", "MOFO_WGRAD_STREAM")}
+        combos = [("k2 on, weight gradients on the main stream", {}), ("k2 off, weight gradients on the main stream", {"MOFO_GEMM_K2": "0"}),
+                  ("k2 on, weight gradients on the side stream", {"MOFO_WGRAD_STREAM": "side"}),
+                  ("k2 off, weight gradients on the side stream", {"MOFO_GEMM_K2": "0", "MOFO_WGRAD_STREAM": "side"})]
+        if any(v is not None for v in user.values()):
+            combos = []                      # the caller fixed a route: nothing to choose
+        ms = {}
+
+        def _use(env):
+            for k in user:
+                os.environ.pop(k, None)
+            os.environ.update(env)
+            model.runtime().invalidate_lists()   # MOFO_WGRAD_STREAM is read while a launch list is recorded
+
+        for name, env in combos:
+            _use(env)
+            step(args.warmup - 1 if args.warmup else 0)      # records the lists again (untimed)
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(5):
+                step(args.warmup - 1 if args.warmup else 0)
+            torch.cuda.synchronize()
+            tb = torch.tensor([(time.perf_counter() - ta) / 5 * 1e3], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tb, op=dist.ReduceOp.MAX)   # every rank sees the same four numbers -> the same choice
+            ms[name] = round(float(tb.item()), 3)
+        if ms:
+            best = min(ms, key=ms.get)
+            _use(dict(combos)[best])
+            step(args.warmup - 1 if args.warmup else 0)
+            dp_ab = {"ms_per_step": ms, "chosen": best}
+            if rank == 0:
+                print("[bench] data-parallel route A/B (ms per step, 5 steps each, max over ranks): " +
+                      "; ".join(f"{k}: {v}" for k, v in ms.items()) + f" -> {best}", file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -309,6 +367,7 @@ def main():
                       "exposed_allreduce_ms_per_rank": exposed_per_rank,
                       "allreduce_value_check": None if ar_check is None else ("ok" if ar_check["ok"] else ("error: " + ar_check["error"] if "error" in ar_check else "fail")),
                       "allreduce_value_check_max_rel": None if ar_check is None or ar_check["max_rel"] != ar_check["max_rel"] else float("%.3e" % ar_check["max_rel"]),
+                      "dp_route_ab": dp_ab, "grad_transport": ("bf16" if os.environ.get("MOFO_GRAD_BF16") == "1" else "f32") if (world > 1 or force_dp) else None,
                       "gpu_phase_s": round(gpu_phase_s, 2), "timed_s": round(dt, 3)}}
 
     if prof is not None:

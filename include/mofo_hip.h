@@ -293,6 +293,10 @@ int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16,
 int mofo_adamw_blocks(long long n);
 int mofo_norm_finalize(const float* partial, int count, float* out_norm, void* stream);
 int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);
+/* the widening cast (exact).  With mofo_cast_bf16 the two ends of the OPTIONAL bf16 gradient transport of the data-parallel exchange
+ * (SURVEY.md 8e "Collective": 188 instead of 377 MB per rank and step; mofo_amd/dist.py, MOFO_GRAD_BF16=1): a range of the flat f32
+ * gradient buffer is narrowed into a wire buffer, all-reduced there and widened back before AdamW reads it. */
+int mofo_cast_f32(const void* src_bf16, float* dst, long long n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -79,6 +79,7 @@ _SIGS = {
     "mofo_adamw_blocks": (_i, [_ll]),
     "mofo_norm_finalize": (_i, [_vp, _i, _vp, _vp]),
     "mofo_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
+    "mofo_cast_f32": (_i, [_vp, _vp, _ll, _vp]),
     "mofo_zero_chunks": (_i, [_vp, _vp, _i, _vp]),
     "mofo_comm_unique_id": (_i, [_vp]),
     "mofo_comm_init": (_i, [_vp, _i, _i, C.POINTER(_vp)]),

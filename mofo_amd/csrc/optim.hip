@@ -115,6 +115,13 @@ __global__ __launch_bounds__(256) void cast_kernel(const float* __restrict__ src
     }
 }
 
+__global__ __launch_bounds__(256) void widen_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long long n4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        const u32x2 v = ((const u32x2*)src)[i];
+        ((f32x4*)dst)[i] = f32x4{bf16lo_to_f32(v[0]), bf16hi_to_f32(v[0]), bf16lo_to_f32(v[1]), bf16hi_to_f32(v[1])};
+    }
+}
+
 int stream_blocks(long long n4) {
     long long b = (n4 + 255) / 256;
     return (int)(b > 2048 ? 2048 : (b < 1 ? 1 : b));
@@ -176,6 +183,14 @@ extern "C" int mofo_cast_bf16(const float* src, void* dst, long long n, void* st
     if (n <= 0 || n % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_cast_bf16: n must be a positive multiple of 4");
     hipLaunchKernelGGL(cast_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, n / 4);
     MOFO_CHECK_LAUNCH("mofo_cast_bf16");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_cast_f32(const void* src_bf16, float* dst, long long n, void* stream) {
+    if (!src_bf16 || !dst) MOFO_FAIL(MOFO_EINVAL, "mofo_cast_f32: null pointer");
+    if (n <= 0 || n % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_cast_f32: n must be a positive multiple of 4");
+    hipLaunchKernelGGL(widen_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src_bf16, dst, n / 4);
+    MOFO_CHECK_LAUNCH("mofo_cast_f32");
     return MOFO_OK;
 }
 

@@ -714,6 +714,15 @@ def cast_bf16(src, dst):
     return dst
 
 
+def cast_f32(src, dst):
+    """bf16 -> f32 (exact): the receiving end of the bf16 gradient transport (dist.GradSync, MOFO_GRAD_BF16=1)"""
+    _chk(src, BF16, "src", 1), _chk(dst, F32, "dst", 1)
+    if src.numel() != dst.numel():
+        raise ValueError("cast_f32: length mismatch")
+    _run("mofo_cast_f32", ("cast",), 6.0 * src.numel(), _p(src), _p(dst), src.numel())
+    return dst
+
+
 def zero_chunks(buf, chunk_ids):
     """zero the listed 1024-element chunks of a flat f32 buffer (chunk_ids: int32 GPU tensor)"""
     _chk(buf, F32, "buf", 1), _chk(chunk_ids, I32, "chunk_ids", 1)

@@ -850,6 +850,12 @@ class PretrainRuntime:
         with torch.cuda.stream(self.side):
             self.segment_hook(idx, lo, hi)
 
+    def invalidate_lists(self):
+        """forget every recorded launch list (and graph): the next call of each sequence runs its Python wrappers again and records
+        anew.  For switches that are read while a list is RECORDED (MOFO_WGRAD_STREAM, ...): bench.py's data-parallel route A/B."""
+        for w in self._ws.values():
+            w.__dict__.pop("_lists", None)
+
     def cached(self, w: NS, tag, fn):
         """run ``fn`` (a fixed launch sequence over workspace ``w``) -- checked and recorded the first time, replayed as a
         flat launch list afterwards (no tensor checks, no Python-side argument marshalling beyond ctypes)"""

@@ -187,6 +187,11 @@ def test_weight_gradient_group_size_by_shape():
     assert _pick_wgrad_blocks(768, 3072) == 3
     assert _pick_wgrad_blocks(1024, 4096) == 1
     assert _pick_wgrad_blocks(128, 512) in (1, 2, 3)
+    # one process (no gradient buckets to hand over): the 256 x 128 ring kernel takes up to seven blocks per launch and ViT-B's 216
+    # units per block fill 5.9 rounds of 256 with seven (84 % with 1 ... 6); ViT-L's 384 per block already fill whole rounds
+    assert _pick_wgrad_blocks(768, 3072, 12, bucketed=False) == 7
+    assert _pick_wgrad_blocks(1024, 4096, 24, bucketed=False) == 1
+    assert _pick_wgrad_blocks(768, 3072, 12, bucketed=True) == 3
 
 
 def test_gradient_segments_tile_the_buffer():
@@ -299,6 +304,98 @@ def test_allreduce_value_check_two_ranks(tmp_path):
         assert r["ok"]["ok"] and r["ok"]["max_rel"] < 1e-6 and r["ok"]["ranges"] == 4
         assert not r["bad"]["ok"] and r["bad"]["max_rel"] > 0.1
         assert tuple(r["bad"]["worst_range"][1:]) == tuple(r["seg1"])          # ... and names the range that was early
+
+
+def _dp8_worker(rank, world, port, out):
+    """eight gloo ranks (the node the multi-GPU records are taken on): the bucket plan, one all-reduce per bucket in completion
+    order, the mean on every rank, and the self-check of the exchange -- with f32 and with bf16 gradient transport"""
+    import torch.distributed as dist
+    from mofo_amd.dist import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    torch.manual_seed(3)
+    model = _tiny_model()
+    rt, st = _cpu_runtime(model)
+    model.runtime = lambda: rt
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(st.total, generator=g)
+    res = {}
+    for name, env in (("f32", "0"), ("bf16", "1")):
+        os.environ["MOFO_GRAD_BF16"] = env
+        sync = GradSync(model, narrow=lambda a, b: b.copy_(a), widen=lambda a, b: b.copy_(a)).install()
+        assert sync.enabled and sync.world_size == world and sync.bf16 == (env == "1")
+
+        def backward():
+            st.grads.copy_(local / world)
+            for idx in range(len(rt.segments)):
+                rt._seg_now(idx)
+
+        backward()
+        launched = list(sync.launched)
+        sync.finish()
+        res[name] = {"grads": st.grads.clone(), "launched": launched,
+                     "check": sync.value_check(backward, tol=1e-4 if env == "0" else 2e-2)}
+    res["local"] = local
+    torch.save(res, out + f".{rank}")
+    os.environ.pop("MOFO_GRAD_BF16", None)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_eight_ranks_f32_and_bf16_transport(tmp_path):
+    import torch.multiprocessing as mp
+    world = 8
+    out = str(tmp_path / "dp8")
+    mp.spawn(_dp8_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(out + f".{i}") for i in range(world)]
+    mean = sum(x["local"] for x in r) / world
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    for i in range(world):
+        assert torch.allclose(r[i]["f32"]["grads"], mean, rtol=1e-5, atol=1e-6)      # SUM of pre-scaled gradients == DDP's mean
+        assert torch.equal(r[i]["f32"]["grads"], r[0]["f32"]["grads"])               # the same bits on every rank
+        assert rel(r[i]["bf16"]["grads"], mean) <= 1e-2                              # bf16 on the wire: within 1e-2 of the f32 transport
+        assert torch.equal(r[i]["bf16"]["grads"], r[0]["bf16"]["grads"])
+        for kind in ("f32", "bf16"):
+            assert [x[0] for x in r[i][kind]["launched"]] == [0, 1, 2, 3]            # one exchange per bucket, in completion order
+            cover = sorted((lo, hi) for _, lo, hi in r[i][kind]["launched"])
+            assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
+            assert r[i][kind]["check"]["ok"] and r[i][kind]["check"]["ranges"] == 4
+        assert r[i]["f32"]["check"]["max_rel"] < 1e-6 and 0 < r[i]["bf16"]["check"]["max_rel"] <= 2e-2
+
+
+def _dp_raise_worker(rank, world, port, out):
+    """value_check when ONE rank's backward raises: every rank gets the error result, nobody is left inside a collective"""
+    import torch.distributed as dist
+    from mofo_amd.dist import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    model = _tiny_model()
+    rt, st = _cpu_runtime(model)
+    model.runtime = lambda: rt
+    sync = GradSync(model).install()
+
+    def backward():
+        if rank == 1:
+            raise RuntimeError("rank 1 is out of memory")
+        st.grads.fill_(1.0)
+        for idx in range(len(rt.segments)):
+            rt._seg_now(idx)
+
+    res = sync.value_check(backward)
+    t = torch.ones(1)
+    dist.all_reduce(t)                          # the group is still in step: the next collective completes on both ranks
+    torch.save({"res": res, "sum": float(t.item())}, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_value_check_survives_a_rank_that_raises(tmp_path):
+    import torch.multiprocessing as mp
+    out = str(tmp_path / "raise")
+    mp.spawn(_dp_raise_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    for i in range(2):
+        r = torch.load(out + f".{i}")
+        assert not r["res"]["ok"] and "error" in r["res"] and r["sum"] == 2.0
+    assert "out of memory" in torch.load(out + ".1")["res"]["error"]
 
 
 def test_device_mask_generator_rank_defaults_and_state(monkeypatch):
