@@ -1042,6 +1042,14 @@ static long long g_route[ROUTE_N];
 
 template <int LA, int LB, int EPI>
 int launch(const GroupP& g, int mi, hipStream_t s) {
+    if constexpr (EPI == MOFO_EPI_RESID_F32 || EPI == MOFO_EPI_RESID_BF16) {
+        // the residual row map is compiled into the epilogues of <= 64-row wave tiles only (epilogue<>: RESID_MAP); mofo_gemm_grouped
+        // never routes a mapped problem to the 128-row wave tiles -- a future routing change or a direct caller gets an error, not
+        // residual rows read from the wrong place
+        if (mi == 16 || mi == 8)
+            for (int i = 0; i < g.count; ++i)
+                if (g.p[i].rows_in > 0) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: a residual row map (rows_in > 0) needs the 128 x 128 / 64 x 128 tile forms");
+    }
     if (mi == 16) {
         if constexpr (gemm8_built<LA, LB, EPI>()) {
             const int total = g.start[g.count];

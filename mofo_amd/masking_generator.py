@@ -105,10 +105,17 @@ class DeviceTubeMaskingGenerator(_TubeGeometry):
 
     def state_dict(self):
         """what a checkpoint needs so that a resumed run continues the mask stream instead of replaying step 0"""
-        return {"seed": self.seed, "clips_drawn": self.clips_drawn}
+        return {"seed": self.seed, "clips_drawn": self.clips_drawn, "world_size": self.world_size}
 
     def load_state_dict(self, state):
+        """``clips_drawn`` counts PER RANK: the global index of a step's first clip is clips_drawn * world_size (+ rank * batch), so a
+        resume under another world size continues at a different place of the stream -- said aloud, not silently"""
         self.seed, self.clips_drawn = int(state["seed"]), int(state["clips_drawn"])
+        saved = int(state.get("world_size", self.world_size))
+        if saved != self.world_size:
+            import warnings
+            warnings.warn(f"device mask generator: checkpoint written with world_size {saved}, resuming with {self.world_size}: the "
+                          f"mask stream continues at global clip {self.clips_drawn * self.world_size} instead of {self.clips_drawn * saved}")
 
     def __call__(self, batch_size, out=None, device=None):
         import torch

@@ -322,6 +322,17 @@ class PretrainRuntime:
         self.wgrad_blocks = max(1, min(7, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
             _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio), dims.enc_depth, bucketed)
         self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
+        # experiment switch MOFO_ENC_BUCKETS="6,3,2,1": encoder blocks per gradient bucket, read ONCE here (plan_segments and
+        # encoder_backward must agree on the bucket ends) and refused aloud when malformed
+        self._bucket_override = None
+        if os.environ.get("MOFO_ENC_BUCKETS") and enc_prefix is not None:
+            try:
+                sizes = [int(x) for x in os.environ["MOFO_ENC_BUCKETS"].split(",")]
+            except ValueError:
+                raise ValueError(f"MOFO_ENC_BUCKETS={os.environ['MOFO_ENC_BUCKETS']!r}: expected comma-separated block counts, e.g. 6,3,2,1") from None
+            if sum(sizes) != dims.enc_depth or any(x <= 0 for x in sizes):
+                raise ValueError(f"MOFO_ENC_BUCKETS={os.environ['MOFO_ENC_BUCKETS']!r}: positive block counts that sum to the encoder depth {dims.enc_depth}")
+            self._bucket_override = sizes
         # forward_only: the fine-tune / feature-extraction forward (modeling_finetune.py) -- no gradient buckets to plan
         self.segments = [] if forward_only else self.plan_segments()
         # The DECODER's residual stream is kept in bf16 (x_full, x_mid, x_out): its GEMMs reduce over 384 / 1536 and are bound
@@ -776,6 +787,13 @@ class PretrainRuntime:
                 ops.host_op(lambda ev=S.done[k]: torch.cuda.current_stream().wait_event(ev))
                 S.used[k] = False
 
+    def enc_buckets(self) -> List[int]:
+        """the encoder's gradient buckets of THIS runtime (the override of MOFO_ENC_BUCKETS, else by depth and group size; groups of
+        more than three blocks exist in one process only, where no bucket is handed over: the plan then follows the three-block rule)"""
+        if self._bucket_override is not None:
+            return list(self._bucket_override)
+        return self._enc_buckets(self.d.enc_depth, min(self.wgrad_blocks, 3))
+
     @staticmethod
     def _enc_buckets(depth: int, group: int = 1) -> List[int]:
         """encoder blocks per gradient bucket, from the top block down: shrinking buckets (12 -> 5, 3, 2, 1, 1) so that the
@@ -785,11 +803,6 @@ class PretrainRuntime:
         6, 3, 2, 1): a bucket end cuts a group short (x1 / x2 groups run at 812 / 834 TFLOP/s against 963 for x3) and every
         bucket costs ~0.08 ms of hand-over (one rank under RCCL, ms per step: 5,3,2,1,1 11.80-11.83 | 6,3,2,1 11.71 | 3,3,3,3 11.68 |
         6,6 11.57 | 12 11.49 | no exchange 11.30 -- the last three expose 85 / 170 / 340 MB of all-reduce after the backward)"""
-        env = os.environ.get("MOFO_ENC_BUCKETS")          # experiment switch: "6,3,2,1" (must sum to the depth)
-        if env:
-            sizes = [int(x) for x in env.split(",")]
-            if sum(sizes) == depth and all(x > 0 for x in sizes):
-                return sizes
         sizes, rem = [], depth
         while rem > 0:
             take = max(1, min(rem, -(-rem * 2 // 5)))
@@ -817,7 +830,7 @@ class PretrainRuntime:
             p = self.enc_prefix
             cur = [p + "norm.weight", p + "norm.bias"]
             i = d.enc_depth - 1
-            buckets = self._enc_buckets(d.enc_depth, self.wgrad_blocks)
+            buckets = self.enc_buckets()
             for bi, nb in enumerate(buckets):
                 for _ in range(nb):
                     cur += self.encW[i].names
@@ -919,7 +932,7 @@ class PretrainRuntime:
         j = 0
         # bucket boundaries (block index after which a gradient range is complete), as plan_segments laid them out
         ends, i_end = set(), d.enc_depth
-        for nb in self._enc_buckets(d.enc_depth, self.wgrad_blocks)[:-1]:
+        for nb in self.enc_buckets()[:-1]:
             i_end -= nb
             ends.add(i_end)
         R = len(S.ring)

@@ -265,8 +265,14 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     if loss_scaler is None:
         raise NotImplementedError("deepspeed checkpoints belong to fine-tuning (out of scope)")
     path = os.path.join(args.output_dir, 'checkpoint-%s.pth' % str(epoch))
-    save_on_master({'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-                    'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': args}, path)
+    state = {'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+             'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': args}
+    # beyond the reference's five keys (its loaders ignore unknown ones): where the device-side mask generator stands, so that a
+    # resumed run continues the mask stream instead of replaying it from step 0 (args.mask_generator: masking_generator.DeviceTubeMaskingGenerator)
+    gen = getattr(args, "mask_generator", None)
+    if gen is not None and hasattr(gen, "state_dict"):
+        state['mask_generator'] = gen.state_dict()
+    save_on_master(state, path)
 
 
 def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, model_ema=None):
@@ -291,4 +297,7 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
         args.start_epoch = state['epoch'] + 1
         if 'scaler' in state:
             loss_scaler.load_state_dict(state['scaler'])
+        gen = getattr(args, "mask_generator", None)
+        if gen is not None and hasattr(gen, "load_state_dict") and 'mask_generator' in state:
+            gen.load_state_dict(state['mask_generator'])
         print("With optim & sched!")

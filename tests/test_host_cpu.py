@@ -443,6 +443,50 @@ def test_finetune_model_schema_and_checkpoint_mapping():
     assert type(feat).__name__ == "VisionTransformer_feat_ext"
 
 
+def test_mask_generator_state_travels_with_the_checkpoint(tmp_path):
+    """a run that draws its masks on the device (masking_generator.DeviceTubeMaskingGenerator, args.mask_generator) resumes the mask
+    stream where the checkpoint left it; a resume under another world size says so"""
+    import types
+    import warnings
+    from functools import partial
+    from mofo_amd import modeling_pretrain as mp, utils
+    from mofo_amd.masking_generator import DeviceTubeMaskingGenerator
+    model = mp.PretrainVisionTransformer(img_size=32, encoder_embed_dim=128, encoder_depth=2, encoder_num_heads=2, decoder_embed_dim=64,
+                                         decoder_depth=1, decoder_num_heads=1, decoder_num_classes=1536, qkv_bias=True,
+                                         norm_layer=partial(torch.nn.LayerNorm, eps=1e-6))
+    opt = types.SimpleNamespace(state_dict=lambda: {"state": {}, "param_groups": []}, load_state_dict=lambda s: None)
+    gen = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=11, rank=1, world_size=2)
+    gen.clips_drawn = 640
+    args = types.SimpleNamespace(output_dir=str(tmp_path), mask_generator=gen)
+    utils.save_model(args, 4, model, model, opt, utils.NativeScalerWithGradNormCount())
+    ck = torch.load(str(tmp_path / "checkpoint-4.pth"), map_location="cpu", weights_only=False)
+    assert ck["mask_generator"] == {"seed": 11, "clips_drawn": 640, "world_size": 2}
+    gen2 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=0, rank=1, world_size=2)
+    args2 = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="", mask_generator=gen2)
+    utils.auto_load_model(args2, model, model, opt, utils.NativeScalerWithGradNormCount())
+    assert (gen2.seed, gen2.clips_drawn, args2.start_epoch) == (11, 640, 5)
+    gen3 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=0, rank=1, world_size=4)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        gen3.load_state_dict(ck["mask_generator"])
+    assert any("world_size 2" in str(x.message) for x in w)
+
+
+def test_bucket_override_is_read_once_and_checked(monkeypatch):
+    """MOFO_ENC_BUCKETS is parsed when the runtime is built (plan_segments and encoder_backward use the same list) and a malformed
+    value is an error at construction, not a silent fall-back"""
+    model = _tiny_model()                      # encoder depth 5
+    monkeypatch.setenv("MOFO_ENC_BUCKETS", "3,2")
+    rt, st = _cpu_runtime(model)
+    assert rt.enc_buckets() == [3, 2] and len(rt.segments) == 3
+    monkeypatch.setenv("MOFO_ENC_BUCKETS", "1,1,1,1,1")
+    assert rt.enc_buckets() == [3, 2]                                  # a later change of the variable does not move the bucket ends
+    for bad in ("3,x", "4,2", "5,0"):
+        monkeypatch.setenv("MOFO_ENC_BUCKETS", bad)
+        with pytest.raises(ValueError, match="MOFO_ENC_BUCKETS"):
+            _cpu_runtime(_tiny_model())
+
+
 def test_saved_checkpoint_feeds_the_reference_finetune_loader(tmp_path):
     """what mofo_amd.utils.save_model writes goes through the reference's fine-tuning loader logic unchanged
     (run_class_finetuning.py:355-381 restated: pick checkpoint['model'], drop a mismatching head, strip 'backbone.' /
