@@ -33,11 +33,7 @@ __device__ unsigned long long g_attn_trace[1 << 18];
 #endif
 
 // raised priority while a wave issues its MFMA groups: the matrix pipe is fed first, other waves' VALU fills the issue gaps
-#ifdef MOFO_ATTN_NOPRIO
-#define ATTN_PRIO(x)
-#else
 #define ATTN_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#endif
 
 constexpr int HD = 64;
 constexpr int RS = 128;              // LDS row stride in bytes (no padding)
@@ -1060,25 +1056,16 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // Forward softmax: a row's reference maximum moves only when a tile's maximum exceeds it by more than this many log2 units
 // (p <= 2^thr instead of <= 1; guide T13).  MOFO_ATTN_RESCALE_THR=0 restores the rescale-on-every-new-maximum form (tests
 // compare both); read per launch.
-// dK/dV pass: start delay (x 64 cycles) of the blocks in odd wave slots; MOFO_ATTN_STAGGER=0 turns it off (read per launch)
-int attn_stagger() {
-    const char* e = getenv("MOFO_ATTN_STAGGER");
-    return e ? atoi(e) : 10;
-}
+// dK/dV pass: start delay (x 64 cycles) of the blocks in odd wave slots
+int attn_stagger() { return 10; }   // (any value from 5 to 30 gave the same -1.5 ... -3 %; 0 = off was the losing side: switch retired in round 5)
 float rescale_thr() {
     const char* e = getenv("MOFO_ATTN_RESCALE_THR");
     return e ? (float)atof(e) : 6.0f;
 }
 
 int pick_nw(int N) {
-    static int forced = -1;
-    if (forced < 0) {
-        const char* e = getenv("MOFO_ATTN_NW");
-        forced = e ? atoi(e) : 0;
-    }
     const int t = (N + 31) / 32;  // 32-row wave tiles
     if (t <= 5) return 5;         // short sequences: one block per (clip, head)
-    if (forced == 4 || forced == 7) return forced;
     return 4;                     // 3 blocks/CU by waves; measured 3 % faster than 7-wave blocks even with a 6 % ragged tail
 }
 }  // namespace

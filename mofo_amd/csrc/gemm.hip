@@ -48,7 +48,8 @@ struct GemmP {
     int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
     int rotate;               // persistent form: rotated reduction order per tile (see gemm_persistent_kernel)
     const float* a_scale_inv; const float* b_scale_inv;   // NT_FP8: per-tensor de-quantisation factors (device scalars)
-    int rotate_tile;          // the same in the one-tile-per-block kernel (MOFO_GEMM_ROTATE_TILE=0 turns it off): small-grid
+    int aux_nt;               // DGELU: read the saved pre-activation with non-temporal loads (set by size)
+    int rotate_tile;          // the same in the one-tile-per-block kernel (on; round 1): small-grid
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
 };
 
@@ -336,8 +337,12 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                     if (FULL || (ncol && m < p.M)) {
                         // dGELU: the saved pre-activation is read here for the last time -- non-temporally, so that it does not push
                         // the gradient this kernel writes (and the next GEMM reads) out of the Infinity Cache
-                        if constexpr (EPI == MOFO_EPI_DGELU_BF16 && MOFO_GEMM_NT_AUX) h[g] = __builtin_nontemporal_load((const u32x4*)(p.aux + (size_t)m * p.ldaux + n));
-                        else h[g] = *(const u32x4*)(p.aux + resid_row(m) * p.ldaux + n);
+                        // ... when it is large (the decoder's 154 MB: 105 vs 112 us); the encoder's 31 MB is read faster with plain loads
+                        // (32.1 vs 33.8 us, profiles/r05_epi_ablate.txt): p.aux_nt, set by size in fill_problem
+                        if constexpr (EPI == MOFO_EPI_DGELU_BF16 && MOFO_GEMM_NT_AUX) {
+                            if (p.aux_nt) h[g] = __builtin_nontemporal_load((const u32x4*)(p.aux + (size_t)m * p.ldaux + n));
+                            else h[g] = *(const u32x4*)(p.aux + (size_t)m * p.ldaux + n);
+                        } else h[g] = *(const u32x4*)(p.aux + resid_row(m) * p.ldaux + n);
                     }
                 }
             }
@@ -371,25 +376,16 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
 #ifndef MOFO_GEMM_NT_H1
 #define MOFO_GEMM_NT_H1 1
 #endif
+// (tried in round 5 and not kept, profiles/r05_epi_ablate.txt / r05_epi_sc1.txt: the activation stored non-temporally too 1.03 x,
+// write-through (sc1) stores 0.90 x at the decoder's shapes)
 #ifndef MOFO_ABL_NO_H1      // timing-only ablation builds (tools/gemm_epi_libs.py): drop the pre-activation / the activation store
 #define MOFO_ABL_NO_H1 0
 #endif
 #ifndef MOFO_ABL_NO_G
 #define MOFO_ABL_NO_G 0
 #endif
-#ifndef MOFO_GEMM_NT_G
-#define MOFO_GEMM_NT_G 0
-#endif
-#ifndef MOFO_GEMM_SC1_H1     // experiment: write-through stores that do not stay in the XCD's L2 (MI355X_MICROARCH.md: plain / nt stores keep the line)
-#define MOFO_GEMM_SC1_H1 0
-#endif
-#ifndef MOFO_GEMM_SC1_G
-#define MOFO_GEMM_SC1_G 0
-#endif
                 if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_ABL_NO_H1) {
                     asm volatile("" ::"v"(o));
-                } else if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_SC1_H1) {
-                    if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((bf16_t*)p.C + (size_t)m * p.ldc + n), "v"(o) : "memory");
                 } else if constexpr (EPI == MOFO_EPI_BIAS_GELU && MOFO_GEMM_NT_H1) {
                     // the pre-activation is not read again before the backward pass: stored non-temporally, it leaves the Infinity
                     // Cache to the activation (C2) that the next GEMM reads (308 MB of outputs per decoder fc1 for 256 MB of cache)
@@ -402,8 +398,6 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                     const f32x2 g2 = gelu_erf2((f32x2){v1[0], v1[1]}), g3 = gelu_erf2((f32x2){v1[2], v1[3]});
                     const u32x4 gg = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
                     if constexpr (MOFO_ABL_NO_G) asm volatile("" ::"v"(gg));
-                    else if constexpr (MOFO_GEMM_SC1_G) { if (ok) asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n), "v"(gg) : "memory"); }
-                    else if constexpr (MOFO_GEMM_NT_G) { if (ok) __builtin_nontemporal_store(gg, (u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n)); }
                     else if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = gg;
                 }
             }
@@ -1067,9 +1061,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         if constexpr (LA == OPL_ROW) {
             const int total = g.start[1];
             const char* e = getenv("MOFO_GEMM_K2_STAG");         // read per call (A/B in one process)
-            const char* er = getenv("MOFO_GEMM_K2_ROT");
-            GemmP pk = g.p[0];
-            if (er) pk.rotate_tile = atoi(er);
+            const GemmP& pk = g.p[0];
             if (!e || atoi(e) != 0) hipLaunchKernelGGL((gemm_k2_kernel<LA, LB, EPI, true>), dim3(total), dim3(512), 0, s, pk, total);
             else hipLaunchKernelGGL((gemm_k2_kernel<LA, LB, EPI, false>), dim3(total), dim3(512), 0, s, pk, total);
             ROUTE(ROUTE_K2);
@@ -1089,12 +1081,7 @@ int launch(const GroupP& g, int mi, hipStream_t s) {
         int var = forced >= 0 ? forced : ((EPI == MOFO_EPI_RESID_F32 && total <= 768) || !can_persist ? 0 : 2);
         if (var == 2 && !can_persist) var = 1;
         // grids of at most two 64-row tiles per CU with a reduction worth splitting: in-block split-K (VAR 3)
-        static int ksplit_on = -1;
-        if (ksplit_on < 0) {
-            const char* e = getenv("MOFO_GEMM_KSPLIT");
-            ksplit_on = e ? atoi(e) : 1;
-        }
-        if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && ((forced < 0 && ksplit_on) || forced == 3)) {
+        if (mi == 2 && can_persist && total <= 512 && p.K >= 1536 && (forced < 0 || forced == 3)) {
             hipLaunchKernelGGL((gemm_ksplit_kernel<LA, LB, EPI>), dim3(total), dim3(512), 0, s, p, total);
             ROUTE(ROUTE_KSPLIT);
         } else if (mi == 8) {
@@ -1190,19 +1177,10 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
         // rotated reduction order (gemm_persistent_kernel): measured per class on one box -- fc1 + GELU forward (12 / 24 n-tiles
         // share an A panel, long epilogue) 126 -> 106 us (decoder), 38.0 -> 37.2 (encoder); neutral for the other wide-N
         // GEMMs; 5-10 % SLOWER for the N = 384 ones (3 n-tiles: little to de-duplicate, and the block's own row panel is no
-        // longer streamed in order).  MOFO_GEMM_ROTATE=0|1 forces it off / on for every persistent GEMM.
-        static int rot = -2;
-        if (rot == -2) {
-            const char* e = getenv("MOFO_GEMM_ROTATE");
-            rot = e ? atoi(e) : -1;
-        }
-        p.rotate = rot >= 0 ? rot : (op == MOFO_GEMM_NT && epi == MOFO_EPI_BIAS_GELU);
-        static int rt = -1;
-        if (rt < 0) {
-            const char* e = getenv("MOFO_GEMM_ROTATE_TILE");
-            rt = e ? atoi(e) : 1;
-        }
-        p.rotate_tile = rt;
+        // longer streamed in order).  (The MOFO_GEMM_ROTATE / _ROTATE_TILE overrides were retired in round 5.)
+        p.rotate = (op == MOFO_GEMM_NT && epi == MOFO_EPI_BIAS_GELU);
+        p.rotate_tile = 1;
+        p.aux_nt = (long long)a->M * a->N * 2 >= (96LL << 20);
     }
     if (a->colsum && !(op == MOFO_GEMM_TN && epi == MOFO_EPI_F32)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: colsum rides on TN + F32 (wgrad) only");
     blocks = ceil_div(a->M, bm) * ceil_div(a->N, bn) * splits;
@@ -1397,8 +1375,7 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
     if (a[0].op != MOFO_GEMM_TN) {
         long long t128 = 0;
         for (int i = 0; i < count; ++i) t128 += (long long)ceil_div(a[i].M, 128) * ceil_div(a[i].N, BN);
-        const char* e = getenv("MOFO_GEMM_MI");
-        if (e ? atoi(e) == 2 : t128 < 400) mi = 2;
+        if (t128 < 400) mi = 2;
         // 256-row tiles (persistent form only: one problem, no split-K / accumulate, not the pos epilogue).  Tile for tile
         // they are 10-15 % SLOWER than 128-row tiles (2 blocks per CU overlap less than 3: dec.fc1 dgrad 64 -> 74 us), so they
         // are used only where they repair the grid quantisation: the encoder's fc1 / fc2-dgrad GEMMs are 960 128-row tiles

@@ -340,9 +340,9 @@ class PretrainRuntime:
         # per ViT-B B=32 step).  The encoder's stream (5 120 token rows, latency-bound kernels) stays f32.  MOFO_DEC_RESID=f32
         # restores the f32 decoder stream (A/B, parity debugging).
         self.dec_resid = F32 if os.environ.get("MOFO_DEC_RESID", "bf16") == "f32" else BF16
-        # MOFO_ENC_RESID=bf16: the same for the encoder -- parity gates pass, the step does not move (11.90 / 11.92 vs 11.96 / 11.87 ms:
-        # its kernels are latency-bound at 5 120 token rows), so the reference's f32 stream stays the default there
-        self.enc_resid = BF16 if os.environ.get("MOFO_ENC_RESID", "f32") == "bf16" else F32
+        # The encoder's stream stays f32 as in the reference: bf16 passed the parity gates and did not move the step (11.90 / 11.92 vs
+        # 11.96 / 11.87 ms, round 2: its kernels are latency-bound at 5 120 token rows); the switch was retired in round 5.
+        self.enc_resid = F32
         # MOFO_FP8=1: the forward Linears fed by a LayerNorm (qkv, fc1) run on OCP e4m3 operands with the block-scaled MFMA
         # (2x the bf16 MFMA rate; BASELINE configs[4] "fp8 MFMA attention/MLP").  Per-tensor scales: weights from their amax
         # every time the shadow changes, activations with delayed scaling (a LayerNorm's scale comes from the amax it saw in
@@ -705,22 +705,9 @@ class PretrainRuntime:
         self._ln_bwd(S.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, dxb_out, None, T.dxbB, W.g_ln2w, W.g_ln2b)
         # attention: x_mid = x_in + proj(attn(LN1(x_in)))
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
-        if n > 512 and self.side2 is not None and os.environ.get("MOFO_ATTN_CONCURRENT", "0") == "1":
-            # OPTIONAL (MOFO_ATTN_CONCURRENT=1; measured neutral next to the weight-gradient stream: 15.1 vs 15.1-15.5 ms):
-            # dQ pass on this stream, dK/dV pass concurrently on a second side stream -- independent once delta is known
-            side2 = self.side2
-            ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
-            ops.host_op(lambda ev=S.att_ready: ev.record(torch.cuda.current_stream()))
-            ops.use_stream(side2)
-            ops.host_op(lambda ev=S.att_ready: side2.wait_event(ev))
-            ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-            ops.host_op(lambda ev=S.att_done: ev.record(side2))
-            ops.use_stream(None)
-            ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-            ops.host_op(lambda ev=S.att_done: torch.cuda.current_stream().wait_event(ev))
-        else:
-            # the three passes of mofo_attention_bwd as their own C-ABI calls (same stream, same kernels): each shows up
-            # under its own name in the per-class timing
+        # the passes of mofo_attention_bwd as their own C-ABI calls (same stream, same kernels): each shows up under its own name in
+        # the per-class timing.  (dQ and dK/dV on two streams measured neutral, round 1; retired in round 5.)
+        if True:
             if n <= 160:
                 # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
                 ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
@@ -849,14 +836,14 @@ class PretrainRuntime:
         if self.segment_hook is None:
             return
         lo, hi = self.segments[idx]
-        if self.side is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+        if self.side is None:
             self.segment_hook(idx, lo, hi)
             return
         # The range's kernels were issued on TWO streams (activation-gradient chain + LayerNorm reduces on the caller's, grouped
         # weight gradients on the side stream) and the consumer (torch.distributed's all-reduce) orders itself behind torch's
         # CURRENT stream: it is handed the range on the side stream, which first waits for an event recorded here on the main
         # stream.  The exchange starts behind both, and the main stream never joins a weight-gradient launch at a bucket end
-        # (that join cost the data-parallel step 0.27 ms; MOFO_SEG_HANDOFF=0 restores it).
+        # (that join cost the data-parallel step 0.27 ms, round 2).
         ev = self._seg_events[idx % len(self._seg_events)]
         ev.record(torch.cuda.current_stream())
         self.side.wait_event(ev)
@@ -946,8 +933,6 @@ class PretrainRuntime:
             if i in ends:
                 if self.segment_hook is not None:      # a bucket consumer needs the range complete here; otherwise the LayerNorm
                     self._ln_flush()                   # partials wait for the ONE reduce launch at the end of the backward
-                    if os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
-                        self._join_side(S)
                 self._seg(seg)
                 seg += 1
         # the patch-embed weight gradient (72 tiles alone) rides in the last blocks' grouped launch
@@ -989,8 +974,7 @@ class PretrainRuntime:
             ops.gemm(ops.GEMM_NN, ops.EPI_BF16, d_e2d, s.bview("encoder_to_decoder.weight"), w.d_encout)
             self._wgrad(d_e2d, enc_out_bf16, s.g2d("encoder_to_decoder.weight"))
             return w.d_encout
-        handoff = self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") == "1"
-        if self.side is not None and handoff and d.dec_dim % 8 == 0 and d.dec_dim <= 512 and os.environ.get("MOFO_ASM_DEFER", "1") == "1":
+        if self.side is not None and d.dec_dim % 8 == 0 and d.dec_dim <= 512:
             # d(mask_token) is needed by nothing before the optimizer (or the bucket hand-over, which is issued on the side stream
             # too): its 24-block reduce goes to the SIDE stream.  On the main stream it sat in the dependent chain behind a CU-filling
             # weight-gradient launch and took ~180 us for 27 us of work (profiles/r02_rocprof_kernel_stats.csv).
@@ -1062,14 +1046,14 @@ class PretrainRuntime:
         if getattr(w, "dec_share", False):
             if not defer_ln:
                 self._ln_flush()
-                if self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+                if self.segment_hook is None:
                     self._join_side(S)
             return w.dec0.dxcat                  # gradient wrt the CAT rows of the decoder input, bf16 [B*n_vis + N, D]
         if S.pending:                      # a decoder without blocks: the head's weight gradient alone
             self._wgrad_flush(S, S.gidx % 2, w.N)
         if not defer_ln:                   # defer_ln: the caller runs the encoder backward next; its final LayerNorm reduce and its
             self._ln_flush()               # join of the (one, in-order) side stream cover this pass's launches as well
-            if self.segment_hook is None or os.environ.get("MOFO_SEG_HANDOFF", "1") != "1":
+            if self.segment_hook is None:
                 self._join_side(S)
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
