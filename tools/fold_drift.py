@@ -26,8 +26,11 @@ def main():
     store = model.runtime().store
     xd, md = x.to(dev), mask.to(dev)
     print(f"ViT-B B=2 (engine fixture inputs): oracle loss {ref_loss:.6f} grad norm {ref_gn:.6f}")
-    for fold in (0, 1, 2):
-        os.environ["MOFO_ATTN_DKV_FOLD"] = str(fold)
+    var = sys.argv[1] if len(sys.argv) > 1 else "MOFO_ATTN_DKV_FOLD"          # e.g. MOFO_ATTN_FOLDQ 0,1 (the dQ pass's exp2 fold)
+    vals = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1, 2]
+    print(f"switch {var}, values {vals}")
+    for fold in vals:
+        os.environ[var] = str(fold)
         loss = model.forward_loss(xd, md)
         store.zero_grads()
         loss.backward()
