@@ -185,13 +185,14 @@ def test_weight_gradient_group_size_by_shape():
     tiles best: ViT-B (432 tiles per block) takes three blocks per launch, ViT-L (768 = one round exactly) one"""
     from mofo_amd.runtime import _pick_wgrad_blocks
     assert _pick_wgrad_blocks(768, 3072) == 3
-    assert _pick_wgrad_blocks(1024, 4096) == 1
+    assert _pick_wgrad_blocks(1024, 4096) == 2
     assert _pick_wgrad_blocks(128, 512) in (1, 2, 3)
     # one process (no gradient buckets to hand over): the 256 x 128 ring kernel takes up to seven blocks per launch and ViT-B's 216
     # units per block fill 5.9 rounds of 256 with seven (84 % with 1 ... 6); ViT-L's 384 per block already fill whole rounds
     assert _pick_wgrad_blocks(768, 3072, 12, bucketed=False) == 7
-    assert _pick_wgrad_blocks(1024, 4096, 24, bucketed=False) == 1
+    assert _pick_wgrad_blocks(1024, 4096, 24, bucketed=False) == 2     # 768 units = three rounds exactly
     assert _pick_wgrad_blocks(768, 3072, 12, bucketed=True) == 3
+    assert _pick_wgrad_blocks(1024, 4096, 24, bucketed=True) == 2
 
 
 def test_gradient_segments_tile_the_buffer():
