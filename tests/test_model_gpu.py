@@ -1082,6 +1082,47 @@ def test_vit_large_32_frames_full_depth(dev, monkeypatch, fp8):
     assert worst[1] < (1.5e-1 if fp8 else 6e-2), worst
 
 
+def test_vit_large_32_frames_batch_of_four(dev, monkeypatch):
+    """BASELINE configs[4]'s model on FOUR clips against the reference classes' own forward / backward on the same four clips
+    (tests/golden/vitl32_full_b4.npz, tools/make_goldens.py --only-l32 --full --batch 4): beyond clip 0 of the one-clip fixture the
+    batch takes the tile forms of 1 280 encoder / 12 544 decoder rows (no 256 x 256 kernel), the shared rows of the first decoder
+    block are summed over four clips and the grouped weight gradients reduce over four clips' tokens.  Loss 1e-3, gradient norm,
+    every per-tensor gradient norm, and the leading elements of six large gradient tensors element-wise."""
+    from oracle import pretrain_oracle as O
+    monkeypatch.setenv("MOFO_FP8", "0")
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=24, enc_heads=16, dec_dim=512, dec_depth=4, dec_heads=8)
+    fx = np.load(os.path.join(G, "vitl32_full_b4.npz"))
+    model, _ = _build(cfg, "xavier", dev)
+    x = O.keyed_clips(4, cfg)
+    np.random.seed(7)
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.9) for _ in range(4)])).bool()
+    assert np.array_equal(mask.numpy().astype(np.uint8), fx["mask"])
+    loss = model.forward_loss(x.to(dev), mask.to(dev))
+    model.runtime().store.zero_grads()
+    loss.backward()
+    gn = float(model.runtime().grad_norm())
+    model.check_status()
+    assert float(loss.detach()) == pytest.approx(float(fx["loss"]), rel=1e-3)
+    assert gn == pytest.approx(float(fx["grad_norm"]), rel=2e-2)
+    g = {n: p.grad for n, p in model.named_parameters()}
+    names = [str(s) for s in fx["names"]]
+    assert len(names) == len(g)
+    worst = ("", 0.0)
+    for i, n in enumerate(names):
+        want = fx["grad_stats"][i, 0]
+        if want < 1e-3 * float(fx["grad_norm"]):
+            continue
+        r = abs(float(g[n].double().norm()) - want) / want
+        if r > worst[1]:
+            worst = (n, r)
+    assert worst[1] < 6e-2, worst
+    for n in ("encoder.blocks.0.attn.qkv.weight", "encoder.blocks.23.mlp.fc2.weight", "encoder.patch_embed.proj.weight",
+              "decoder.blocks.0.attn.qkv.weight", "decoder.blocks.3.mlp.fc1.weight", "decoder.head.weight", "encoder_to_decoder.weight"):
+        i = names.index(n)
+        got = g[n].detach().float().flatten()[:16].cpu().numpy()
+        assert np.abs(got - fx["grad_head"][i]).max() <= 6e-2 * fx["grad_stats"][i, 2], n     # against the tensor's largest element
+
+
 def test_vitl32_b32_step_parity(dev, monkeypatch):
     """BASELINE configs[4]'s model at the batch bench.py --model vitl32 times (ViT-L, 32 frames, 32 clips, bf16) WITH DEFAULT
     ROUTING: at 10 240 encoder / 100 352 decoder rows the forward GEMMs go through the 256 x 256 counted-vmcnt kernel (gemm8) and the

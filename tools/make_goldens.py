@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--only-bb-engine", action="store_true", help="only engine_vitb_bb.npz: one step of the reference's own train_one_epoch_BB")
     ap.add_argument("--only-l32", action="store_true", help="only vitl32.npz: ViT-L widths at 32 frames (BASELINE config 4 shapes) through the reference classes")
     ap.add_argument("--full", action="store_true", help="with --only-l32: the FULL ViT-L depth (24 + 4 blocks) -> vitl32_full.npz (SURVEY 8c fixture F6)")
+    ap.add_argument("--batch", type=int, default=1, help="with --only-l32 --full: clips in the batch (4 -> vitl32_full_b4.npz: the routes a batch takes, pinned beyond clip 0)")
     ap.add_argument("--only-clip", action="store_true", help="only tiny_clip.npz: steps through the reference scaler with clip_grad")
     ap.add_argument("--only-ckpt", action="store_true", help="only ckpt_tiny.npz: a checkpoint WRITTEN by the reference's utils.save_model after two steps")
     args = ap.parse_args()
@@ -455,11 +456,13 @@ def make_l32(args, ref_mp, ref_mf, O):
     model.load_state_dict(P, strict=True)
     model.encoder.pos_embed = ref_mf.get_sinusoid_encoding_table(cfg.num_patches, cfg.enc_dim)
     model.pos_embed = ref_mf.get_sinusoid_encoding_table(cfg.num_patches, cfg.dec_dim)
-    videos = O.keyed_clips(1, cfg)
+    nb = max(1, int(getattr(args, "batch", 1))) if full else 1
+    videos = O.keyed_clips(nb, cfg)
     np.random.seed(7)
     import masking_generator as ref_mg
-    mask = torch.from_numpy(ref_mg.TubeMaskingGenerator(cfg.grid, 0.9)()[None]).bool()
-    assert mask.shape[1] == 3136 and int((~mask).sum()) == 320
+    mgen = ref_mg.TubeMaskingGenerator(cfg.grid, 0.9)
+    mask = torch.from_numpy(np.stack([mgen() for _ in range(nb)])).bool()      # clip 0's mask is the one-clip fixture's
+    assert mask.shape[1] == 3136 and all(int((~m).sum()) == 320 for m in mask)
     labels = O.build_targets(videos, mask, cfg)          # the target builder is pinned by engine_vitb.npz (reference engine capture)
     out = model(videos, mask)
     loss = torch.nn.MSELoss()(out, labels)
@@ -467,7 +470,8 @@ def make_l32(args, ref_mp, ref_mf, O):
     grads = {k: p.grad.detach() for k, p in model.named_parameters()}
     names, gstat, ghead = tensor_stats(grads)
     gn = float(torch.sqrt(sum(g.double().pow(2).sum() for g in grads.values())))
-    np.savez_compressed(os.path.join(args.out, "vitl32_full.npz" if full else "vitl32.npz"), mask=mask.numpy().astype(np.uint8), loss=np.array(loss.item()), grad_norm=np.array(gn),
+    fname = ("vitl32_full.npz" if nb == 1 else f"vitl32_full_b{nb}.npz") if full else "vitl32.npz"
+    np.savez_compressed(os.path.join(args.out, fname), mask=mask.numpy().astype(np.uint8), loss=np.array(loss.item()), grad_norm=np.array(gn),
                         names=np.array(names), grad_stats=gstat, grad_head=ghead, out_slice=out[:, :6, :48].detach().numpy(),
                         out_sum=np.array(out.detach().double().sum().item()))
     print("vitl32: loss", loss.item(), "grad norm", gn, "out_sum", out.detach().double().sum().item())
