@@ -358,8 +358,8 @@ def main():
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
            "dtype": "bf16" if not args.fp8 else "fp8 e4m3 (forward qkv / fc1 GEMMs) + bf16", "data": "synthetic",
-           "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate/"
-                                  "residual/optimizer, full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
+           "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate / "
+                                  "encoder residual stream / optimizer (decoder residual stream bf16), full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),
                       "step_mfma_frac": round(clips_per_s / world * step_flop / PEAK_BF16, 4),
                       "ms_per_step_median": round(float(np.median(per_step_ms)), 3), "rccl_ranks": rccl_ranks, "backend": backend if (world > 1 or force_dp) else None,
