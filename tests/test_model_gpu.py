@@ -569,7 +569,8 @@ def test_vitb_b32_step_parity(dev):
     routes = ops.gemm_route_counts()
     # the B = 32 step really ran the forms the headline benchmark runs: persistent 128- and 256-row tiles, the one-tile-per-CU
     # split-K ring kernel (encoder fc2 / dfc1 / dqkv + patch embed: 12 + 12 + 12 + 1 launches), one-tile blocks (weight gradients)
-    assert routes["persistent"] > 0 and routes["persistent256"] > 0 and routes["k2"] == 37 and routes["tile"] > 0, routes
+    # ... and (round 5) the 256 x 128 ring kernel: the encoder's weight gradients as groups of 7 + 5 blocks (+ the patch embed's)
+    assert routes["persistent"] > 0 and routes["persistent256"] > 0 and routes["k2"] == 37 and routes["tile"] > 0 and routes["r3"] == 2, routes
     assert float(loss) == pytest.approx(ref_loss, rel=1e-3)
     assert float(loss) == pytest.approx(float(np.mean(pair_losses)), rel=5e-4)
     total = float(acc.double().norm())
@@ -1126,7 +1127,7 @@ def test_vit_large_32_frames_batch_of_four(dev, monkeypatch):
 def test_vitl32_b32_step_parity(dev, monkeypatch):
     """BASELINE configs[4]'s model at the batch bench.py --model vitl32 times (ViT-L, 32 frames, 32 clips, bf16) WITH DEFAULT
     ROUTING: at 10 240 encoder / 100 352 decoder rows the forward GEMMs go through the 256 x 256 counted-vmcnt kernel (gemm8) and the
-    encoder's weight gradients run one block per grouped launch -- forms the B = 1 fixture test never reaches.  Clip 0 alone is
+    encoder's weight gradients run two blocks per grouped launch on the 256 x 128 ring kernel -- forms the B = 1 fixture test never reaches.  Clip 0 alone is
     pinned to the reference (vitl32_full.npz); the B = 32 loss is the mean of the 32 one-clip HIP losses and the B = 32 gradient
     the mean of the 32 one-clip HIP gradients (loss = mean over clips), tensor by tensor."""
     from mofo_amd import ops
@@ -1139,7 +1140,7 @@ def test_vitl32_b32_step_parity(dev, monkeypatch):
     B = 32
     model, _ = _build(cfg, "xavier", dev)
     rt = model.runtime()
-    assert rt.wgrad_blocks == 1
+    assert rt.wgrad_blocks == 2      # round 5: two blocks' weight gradients = 768 units = three whole rounds of the 256 x 128 ring kernel
     store = rt.store
     x = O.keyed_clips(B, cfg)
     np.random.seed(7)
@@ -1165,6 +1166,7 @@ def test_vitl32_b32_step_parity(dev, monkeypatch):
     model.check_status()
     routes = ops.gemm_route_counts()
     assert routes["gemm8"] >= 4 * 24, routes                        # encoder qkv / proj / fc1 / fc2 forward of every block at least
+    assert routes["r3"] >= 11, routes                               # ... and the encoder's weight gradients on the ring kernel, two blocks per launch
     assert float(loss) == pytest.approx(float(np.mean(ones)), rel=5e-4)
     total = float(acc.double().norm())
     assert float(rt.grad_norm()) == pytest.approx(total, rel=1e-2)
