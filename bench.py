@@ -111,8 +111,8 @@ def main():
     ap.add_argument("--input", choices=["f32", "uint8"], default="f32",
                     help="f32: the model's input contract (normalised clips in HBM); uint8: the loader's frame stack [B,H,W,T*3], "
                          "normalised inside the gather / target kernels (side measurement)")
-    ap.add_argument("--fp8", action="store_true", help="side measurement (BASELINE configs[4]): the LayerNorm-fed forward Linears (qkv, fc1) on OCP "
-                                                       "e4m3 operands with the block-scaled MFMA; everything else bf16")
+    ap.add_argument("--fp8", action="store_true", help="side measurement (BASELINE configs[4]): the four forward Linears of every block (qkv, proj, fc1, "
+                                                       "fc2) on OCP e4m3 operands with the block-scaled MFMA; attention and the backward bf16")
     ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
                     help="vitb16: the headline workload (BASELINE configs[1]/[2]); vitl32: ViT-L, 32 frames (configs[4] in bf16; side measurement)")
     args = ap.parse_args()
@@ -185,7 +185,7 @@ def main():
     from mofo_amd.masking_generator import TubeMaskingGenerator, TubeMaskingGenerator_BB
 
     torch.manual_seed(0)           # identical random-init replica on every rank (DDP would broadcast rank 0's)
-    if args.model == "vitl32":     # BASELINE configs[4] shapes (bf16 here; its fp8 path is not built): 3136 tokens, 320 visible
+    if args.model == "vitl32":     # BASELINE configs[4] shapes (--fp8: its e4m3 forward Linears): 3136 tokens, 320 visible
         model = mp.pretrain_videomae_large_patch16_224(decoder_depth=4, num_frames=32).to(dev)
         B, N, n_vis, grid, step_flop, enc_flop, label = args.batch, 3136, 320, (16, 14, 14), 1104.8e9, 610.0e9, "ViT-L (enc 24x1024, dec 4x512) 32x224x224"
         args.no_cpu_baseline = True
@@ -357,7 +357,7 @@ def main():
     out = {"metric": "clips/sec (16x3x224x224, mask 90%) ViT-B pretrain step" if args.model == "vitb16" else "clips/sec (32x3x224x224, mask 90%) ViT-L pretrain step", "value": round(clips_per_s, 2), "unit": "clips/s",
            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-           "dtype": "bf16" if not args.fp8 else "fp8 e4m3 (forward qkv / fc1 GEMMs) + bf16", "data": "synthetic",
+           "dtype": "bf16" if not args.fp8 else "fp8 e4m3 (forward qkv / proj / fc1 / fc2 GEMMs) + bf16", "data": "synthetic",
            "config": {"workload": label + " " + ("tube" if args.mask == "tube" else "motion-BB") + " mask 0.9, per-GPU batch %d, bf16 MFMA + fp32 accumulate / "
                                   "encoder residual stream / optimizer (decoder residual stream bf16), full train step (target+fwd+loss+bwd+grad-norm+AdamW)" % B,
                       "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "mask": args.mask, "input": args.input, "final_loss": round(last, 5),

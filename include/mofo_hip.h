@@ -20,7 +20,9 @@ extern "C" {
 
 /* 2 (round 5): mofo_attention_delta_zero_dq and mofo_attention_bwd_onepass are gone (round 4), mofo_gemm_grouped_plan is new and
  * mofo_gemm_grouped takes up to 32 weight-gradient problems; INTEGRATION.md lists every change of the exported set. */
-#define MOFO_ABI_VERSION 2
+/* 3 (round 5): mofo_gemm_args grew (C8, ldc8, q_scale, q_amax: the e4m3 copy of fc1's activation); MOFO_GEMM_NT_FP8 takes the
+ * residual epilogues; new entries mofo_attention_fwd_q8, mofo_adamw_q8. */
+#define MOFO_ABI_VERSION 3
 
 /* ---- library ---- */
 int mofo_version(void);
@@ -35,7 +37,8 @@ enum { MOFO_GEMM_NT = 0, /* C[m,n] = sum_k A[m,k] B[n,k]  forward  */
        MOFO_GEMM_NT_FP8 = 3 /* NT on e4m3 operands (see below)       */ };
 /* MOFO_GEMM_NT_FP8 (op 3): the NT form on OCP e4m3 operands (1 byte per element, lda / ldb in bytes, K a multiple of 128),
  * block-scaled MFMA (v_mfma_scale_f32_16x16x128_f8f6f4, unit block scales: 2x the bf16 MFMA rate), f32 accumulate; the
- * per-tensor de-quantisation factors are read on the device.  Epilogues BF16 and BIAS_GELU.  BASELINE configs[4]'s fp8 forward. */
+ * per-tensor de-quantisation factors are read on the device.  Epilogues BF16, BIAS_GELU (optionally with an e4m3 copy of the
+ * activation, C8), RESID_F32, RESID_BF16: the four forward Linears of a transformer block.  BASELINE configs[4]'s fp8 forward. */
 enum { MOFO_EPI_BF16 = 0,       /* C(bf16) = acc (+bias[n])                                            */
        MOFO_EPI_BIAS_GELU = 1,  /* h = acc+bias; C(bf16)=h; C2(bf16)=gelu_erf(h)   (fc1 + nn.GELU)      */
        MOFO_EPI_RESID_F32 = 2,  /* C(f32) = resid(f32) + acc (+bias)   (proj / fc2 + residual add)      */
@@ -66,6 +69,9 @@ typedef struct mofo_gemm_args {
     int colsum_skip_lo, colsum_skip_hi; /* rows m in [lo,hi) of colsum are left untouched (k third of the fused qkv bias) */
     const float* a_scale_inv;     /* NT_FP8: device scalars; C = epilogue(a_scale_inv[0] * b_scale_inv[0] * sum_k A8 B8) */
     const float* b_scale_inv;
+    void* C8; int ldc8;           /* NT_FP8 + BIAS_GELU (ABI 3): e4m3 copy of the activation C2, sat(gelu * q_scale[0]), the A operand of an */
+    const float* q_scale;         /* fp8 fc2; q_scale = device scalar (delayed scaling), q_amax = MOFO_FP8_AMAX_STRIPES floats that        */
+    float* q_amax;                /* collect max|gelu| of this launch (folded by mofo_fp8_update_scales); C8 = NULL: no copy              */
 } mofo_gemm_args;
 int mofo_gemm(const mofo_gemm_args* args, void* stream);
 /* up to 13 problems (32 for TN + F32 weight-gradient groups) of ONE (op, epilogue) kind in one launch (e.g. the four weight-gradient GEMMs of three transformer blocks
@@ -149,6 +155,11 @@ int mofo_attention_bwd_dkv(const void* qkv, int ldqkv, const void* dout, int ldd
  * written: clear them).  q_begin = 0 is exactly the entries above. */
 int mofo_attention_fwd_range(const void* qkv, int ldqkv, int B, int N, int H, float scale, int q_begin,
                              void* out, int ldo, float* lse2, void* stream);
+/* mofo_attention_fwd_range that ALSO writes the output rows as OCP e4m3 (out_e4m3 [B * (N - q_begin), ldo8 bytes] = sat(O * q_scale[0])):
+ * the A operand of an fp8 proj GEMM (BASELINE configs[4]).  q_scale: device scalar (delayed scaling); q_amax: MOFO_FP8_AMAX_STRIPES
+ * floats collecting max|O| of this launch (mofo_fp8_update_scales folds them into the next step's scale). */
+int mofo_attention_fwd_q8(const void* qkv, int ldqkv, int B, int N, int H, float scale, int q_begin, void* out, int ldo, float* lse2,
+                          void* out_e4m3, int ldo8, const float* q_scale, float* q_amax, void* stream);
 int mofo_attention_delta_range(const void* out, int ldo, const void* dout, int lddo, int B, int N, int H, int q_begin, float* delta,
                                void* stream);
 int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
@@ -186,6 +197,11 @@ int mofo_fp8_quantize_bf16(const void* x_bf16, long long n, const float* scale, 
 /* delayed scaling: a_i = max over amax[i][0 .. MOFO_FP8_AMAX_STRIPES); scales[2i] = 448 / (a_i * margin), scales[2i+1] = its inverse;
  * the stripes are cleared.  a_i == 0 keeps the old pair */
 int mofo_fp8_update_scales(float* amax, float* scales, int n, float margin, void* stream);
+/* weights, delayed scaling through the optimizer (mofo_adamw_q8): once per step BEFORE its first update launch --
+ * scale[i] = 448 / amax[i], scale_inv[i] = amax[i] / 448, amax[i] = 0; amax[i] == 0 keeps the old pair.  The gate words are those of
+ * the update that follows (mofo_adamw_gated): a declined update leaves the e4m3 shadow untouched, and so does this its scales */
+int mofo_fp8_roll_scales(float* amax, float* scale, float* scale_inv, int n, const float* gate_finite, const int* gate_zero,
+                         const float* gate_one, void* stream);
 
 /* ---- masks -> index lists: replaces the boolean gathers x[~mask] / pos[mask] of modeling_pretrain.py:90,261-262
  * and engine_for_pretraining.py:63 (which cost a device->host sync in the reference).  mask: uint8 [B,N], 1 = masked.
@@ -290,6 +306,16 @@ int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16,
                      float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
                      const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
                      const float* gate_finite, const int* gate_zero, const float* gate_one, void* stream);
+/* mofo_adamw_gated that also writes the OCP e4m3 shadow of the fp8 forward's GEMM weights (BASELINE configs[4]) from the pass that
+ * holds the new weight anyway: chunk_seg[n / 1024] = weight-matrix index of each 1024-element chunk or -1 (as mofo_fp8_quantize_segments),
+ * p_e4m3[i] = sat(bf16(p[i]) * w_scale[seg]) with the DELAYED scale of mofo_fp8_roll_scales, w_amax[seg] = max |bf16(p)| of the new
+ * values (atomic max; rolled into the next step's scale).  p_bf16 is required.  Range-by-range calls pass the slices of every
+ * per-element / per-chunk array and the WHOLE w_scale / w_amax arrays. */
+int mofo_adamw_q8(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                  float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                  const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                  const float* gate_finite, const int* gate_zero, const float* gate_one, const short* chunk_seg,
+                  const float* w_scale, float* w_amax, void* p_e4m3, void* stream);
 int mofo_adamw_blocks(long long n);
 int mofo_norm_finalize(const float* partial, int count, float* out_norm, void* stream);
 int mofo_cast_bf16(const float* src, void* dst_bf16, long long n, void* stream);

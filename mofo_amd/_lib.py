@@ -27,7 +27,7 @@ class GemmArgs(C.Structure):
                 ("bias", _vp), ("resid", _vp), ("ldr", _i), ("aux", _vp), ("ldaux", _i),
                 ("pos", _vp), ("ldpos", _i), ("row_idx", _vp), ("rows_in", _i), ("rows_out", _i), ("row_off", _i),
                 ("splits", _i), ("accumulate", _i), ("colsum", _vp), ("colsum_skip_lo", _i), ("colsum_skip_hi", _i),
-                ("a_scale_inv", _vp), ("b_scale_inv", _vp)]
+                ("a_scale_inv", _vp), ("b_scale_inv", _vp), ("C8", _vp), ("ldc8", _i), ("q_scale", _vp), ("q_amax", _vp)]
 
 
 _SIGS = {
@@ -54,6 +54,7 @@ _SIGS = {
     "mofo_attention_bwd_dq": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_attention_bwd_dkv": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _i, _vp]),
     "mofo_attention_fwd_range": (_i, [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp]),
+    "mofo_attention_fwd_q8": (_i, [_vp, _i, _i, _i, _i, _f, _i, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp]),
     "mofo_attention_delta_range": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "mofo_attention_bwd_dq_range": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
     "mofo_attention_bwd_dq_delta_range": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp, _i, _vp]),
@@ -76,6 +77,8 @@ _SIGS = {
     "mofo_sumsq": (_i, [_vp, _ll, _vp, _vp, _vp]),
     "mofo_adamw": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp, _vp]),
     "mofo_adamw_gated": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mofo_adamw_q8": (_i, [_vp, _vp, _vp, _vp, _vp, _ll, _vp, _f, _f, _f, _f, _f, _f, _f, _i, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "mofo_fp8_roll_scales": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "mofo_adamw_blocks": (_i, [_ll]),
     "mofo_norm_finalize": (_i, [_vp, _i, _vp, _vp]),
     "mofo_cast_bf16": (_i, [_vp, _vp, _ll, _vp]),
@@ -103,7 +106,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mofo_version() != 2:
+        if lib.mofo_version() != 3:
             raise RuntimeError("libmofo_hip.so ABI version mismatch")
         _lib = lib
     return _lib

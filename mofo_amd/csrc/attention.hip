@@ -142,7 +142,11 @@ __device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a qu
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
 // and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
-template <int NW, int MODE, bool WHOLE, bool U2 = false>
+// Q8 (MODE 0 only; BASELINE configs[4]): the output rows also go out as OCP e4m3, sat(O * q_scale[0]) -- the A operand of an fp8 proj
+// GEMM -- and max|O| of the launch goes to the MOFO_FP8_AMAX_STRIPES stripes (delayed scaling, as the quantising LayerNorm).  The
+// forward leaves the backward's parameters unused and borrows three of them: dqkv / lddqkv = the e4m3 destination and its leading
+// dimension in bytes, dout = the device scalar q_scale, delta = the stripes.
+template <int NW, int MODE, bool WHOLE, bool U2 = false, bool Q8 = false>
 __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
@@ -349,6 +353,31 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     }
     if (nfull < nkt) tile(nfull, std::true_type{}, NoPar{});
 
+    if constexpr (MODE == 0 && Q8) {
+        const float lt = l + __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / lt;
+        const float qs = ((const float*)dout)[0];
+        float am = 0.f;
+        if (qvalid) {
+            store_T(out + ((size_t)b * nq + (qi - qb)) * ldo + h * HD, o0, o1, inv, hh);
+            if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m * c + fast_log2(lt);
+            unsigned char* o8 = (unsigned char*)dqkv + ((size_t)b * nq + (qi - qb)) * lddqkv + h * HD;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                const f32x16& a = dt ? o1 : o0;
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const float v0 = a[4 * rg] * inv, v1 = a[4 * rg + 1] * inv, v2 = a[4 * rg + 2] * inv, v3 = a[4 * rg + 3] * inv;
+                    am = fmaxf(am, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+                    *(uint32_t*)(o8 + 32 * dt + 8 * rg + 4 * hh) = pack4_e4m3(v0 * qs, v1 * qs, v2 * qs, v3 * qs);
+                }
+            }
+        }
+        am = wave_max(am);      // every lane is still here (no early return above)
+        float* slot = delta + ((blockIdx.x * NW + wave) & (MOFO_FP8_AMAX_STRIPES - 1));
+        if (lane == 0 && am > *(volatile const float*)slot) atomicMax((unsigned*)slot, __float_as_uint(am));
+        return;
+    }
     if (!qvalid) return;
     if constexpr (MODE == 0) {
         const float lt = l + __shfl_xor(l, 32, 64);
@@ -1070,9 +1099,10 @@ int pick_nw(int N) {
 }
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false); } else { LAUNCH_Q_(NW, MODE, false, true); } } while (0)
-#define LAUNCH_Q_(NW, MODE, WH, U2)                                                                                     \
-    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N - q_begin, 32 * NW)), dim3(NW * 64), 0, s, \
+#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false, false); } else { LAUNCH_Q_(NW, MODE, false, true, false); } } while (0)
+#define LAUNCH_Q8(NW) do { if (N <= 160) { LAUNCH_Q_(NW, 0, true, false, true); } else { LAUNCH_Q_(NW, 0, false, true, true); } } while (0)
+#define LAUNCH_Q_(NW, MODE, WH, U2, Q8)                                                                                 \
+    hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2, Q8>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N - q_begin, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N - q_begin, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
                        (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr(), q_begin)
 
@@ -1110,6 +1140,25 @@ extern "C" int mofo_attention_fwd_range(const void* qkv, int ldqkv, int B, int N
         default: LAUNCH_Q(4, 0); break;
     }
     MOFO_CHECK_LAUNCH("mofo_attention_fwd");
+    return MOFO_OK;
+}
+
+extern "C" int mofo_attention_fwd_q8(const void* qkv, int ldqkv, int B, int N, int H, float scale, int q_begin, void* out, int ldo,
+                                     float* lse2, void* out_e4m3, int ldo8, const float* q_scale, float* q_amax, void* stream) {
+    int rc = check_common("mofo_attention_fwd_q8", qkv, ldqkv, B, N, H);
+    if (rc) return rc;
+    if ((rc = check_range("mofo_attention_fwd_q8", N, q_begin))) return rc;
+    if (!out || !lse2 || !out_e4m3 || !q_scale || !q_amax) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_fwd_q8: null pointer");
+    if (ldo < H * 64 || ldo % 4 || ldo8 < H * 64 || ldo8 % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd_q8: bad ldo=%d / ldo8=%d", ldo, ldo8);
+    hipStream_t s = (hipStream_t)stream;
+    const float c = scale * 1.4426950408889634f;
+    // the forward kernel's unused backward parameters carry the e4m3 destination, its scale and the amax stripes (attn_q_kernel: Q8)
+    const void* dout = q_scale; int lddo = 0; void* dqkv = out_e4m3; int lddqkv = ldo8; float* delta = q_amax;
+    switch (pick_nw(N)) {
+        case 5: LAUNCH_Q8(5); break;
+        default: LAUNCH_Q8(4); break;
+    }
+    MOFO_CHECK_LAUNCH("mofo_attention_fwd_q8");
     return MOFO_OK;
 }
 

@@ -48,6 +48,8 @@ struct GemmP {
     int colsum_skip_lo, colsum_skip_hi;   // rows m in [lo,hi) are not written (the k third of the fused qkv bias)
     int rotate;               // persistent form: rotated reduction order per tile (see gemm_persistent_kernel)
     const float* a_scale_inv; const float* b_scale_inv;   // NT_FP8: per-tensor de-quantisation factors (device scalars)
+    unsigned char* C8; int ldc8;          // NT_FP8 + BIAS_GELU: e4m3 copy of the activation (C2), sat(gelu * q_scale[0]); or null
+    const float* q_scale; float* q_amax;  // ... its scale (device scalar) and the MOFO_FP8_AMAX_STRIPES stripes that collect max|gelu|
     int aux_nt;               // DGELU: read the saved pre-activation with non-temporal loads (set by size)
     int rotate_tile;          // the same in the one-tile-per-block kernel (on; round 1): small-grid
                               // residual GEMMs 1.39 -> 1.35 ms/step, wgrad neutral
@@ -323,6 +325,13 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
         }
         constexpr int NIT = PROWS / 8;          // row groups (8 rows x 128 B per wave-instruction) per pass
         constexpr int NG = WROWS / 8;           // ... per wave tile; the pre-activation rows of all of them are fetched up front
+        // e4m3 copy of the activation for an fp8 fc2 (the e4m3 kernels only): quantised from the f32 values with the DELAYED scale
+        // q_scale[0] (set from the maximum the previous forward saw); this forward's maximum goes to the stripes of q_amax
+        constexpr bool Q8OUT = SCALED && EPI == MOFO_EPI_BIAS_GELU;
+        float q8s = 1.f, q8am = 0.f;
+        if constexpr (Q8OUT) {
+            if (p.C8) q8s = p.q_scale[0];
+        }
         auto run = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
             u32x4 h[NG];
@@ -399,12 +408,27 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
                     const u32x4 gg = {pack_bf16x2(g0[0], g0[1]), pack_bf16x2(g1[0], g1[1]), pack_bf16x2(g2[0], g2[1]), pack_bf16x2(g3[0], g3[1])};
                     if constexpr (MOFO_ABL_NO_G) asm volatile("" ::"v"(gg));
                     else if (ok) *(u32x4*)((bf16_t*)p.C2 + (size_t)m * p.ldc2 + n) = gg;
+                    if constexpr (Q8OUT) {
+                        if (p.C8 && ok) {
+                            q8am = fmaxf(fmaxf(q8am, fmaxf(fmaxf(fabsf(g0[0]), fabsf(g0[1])), fmaxf(fabsf(g1[0]), fabsf(g1[1])))),
+                                         fmaxf(fmaxf(fabsf(g2[0]), fabsf(g2[1])), fmaxf(fabsf(g3[0]), fabsf(g3[1]))));
+                            *(u32x2*)(p.C8 + (size_t)m * p.ldc8 + n) = u32x2{pack4_e4m3(g0[0] * q8s, g0[1] * q8s, g1[0] * q8s, g1[1] * q8s),
+                                                                              pack4_e4m3(g2[0] * q8s, g2[1] * q8s, g3[0] * q8s, g3[1] * q8s)};
+                        }
+                    }
                 }
             }
             __builtin_amdgcn_wave_barrier();
         };
         if (full_tile) run(std::true_type{});
         else run(std::false_type{});
+        if constexpr (Q8OUT) {
+            if (p.C8) {      // the running maximum is read first: after the first tiles almost no wave issues the atomic (layernorm.hip)
+                q8am = wave_max(q8am);
+                float* slot = p.q_amax + ((blockIdx.x * 4 + (threadIdx.x >> 6)) & (MOFO_FP8_AMAX_STRIPES - 1));
+                if (lane == 0 && q8am > *(volatile const float*)slot) atomicMax((unsigned*)slot, __float_as_uint(q8am));
+            }
+        }
     } else if (EPI == MOFO_EPI_F32 && p.atomic) {
 #pragma unroll
         for (int ps = 0; ps < PASSES; ++ps) {
@@ -431,7 +455,7 @@ __device__ __forceinline__ void epilogue(const GemmP& p, f32x4 (&acc)[MI][4], fl
         if (p.bias && ncol) bv = *(const f32x4*)(p.bias + n);
         constexpr int NIT = PROWS / 4;          // row groups (4 rows x 256 B per wave-instruction) per pass
         constexpr int NG = WROWS / 4;           // ... per wave tile
-        constexpr int CH = NG < 8 ? NG : 8;     // row groups per residual prefetch chunk (32 VGPRs)
+        constexpr int CH = NG < 8 ? NG : (SCALED ? 4 : 8);   // row groups per residual prefetch chunk (32 VGPRs; 16 beside the e4m3 kernel's 8-register fragments)
         static_assert(NG % CH == 0, "chunking");
         auto run = [&](auto full_tag) {
             constexpr bool FULL = decltype(full_tag)::value;
@@ -992,6 +1016,95 @@ __global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
                                (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false, alpha);
 }
 
+// PERSISTENT e4m3 form (round 5): the bf16 persistent kernel's schedule on one-byte operands.  A 128-B LDS row holds 128 reduction
+// elements instead of 64 and one v_mfma_scale_f32_16x16x128_f8f6f4 (8 passes) does the work of four bf16 16x16x32 MFMAs (4 passes
+// each): a k-stage costs the same LDS bytes, fragment registers (8 VGPRs per 16-row sub-tile) and matrix-pipe cycles as a bf16
+// k-stage and covers TWICE the reduction.  One LDS stage + register double buffering (3 blocks / CU at MI <= 4), the next tile's
+// first k-stage issued from the last k-iteration, counted wait at the tile start, wave-private epilogue staging: see
+// gemm_persistent_kernel.  Every forward Linear of a block runs here under MOFO_FP8=1: qkv (BF16), proj / fc2 (RESID_*), fc1
+// (BIAS_GELU, which also writes the e4m3 copy of its activation for fc2).
+template <int EPI, int MI>
+__global__ __launch_bounds__(256, 3) void gemm_fp8_persistent_kernel(GemmP p, int total) {
+    static_assert(MI == 2 || MI == 4, "64- and 128-row tiles (256-row tiles: slower on 7 of 8 ViT-L shapes and 4-22 spilled VGPRs)");
+    constexpr int BMT = 32 * MI;
+    constexpr int A_BYTES = BMT * 128;
+    constexpr int STG = A_BYTES + 128 * 128;
+    constexpr int EP_BYTES = 4 * 16 * 64 * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STG + EP_BYTES];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int nk = p.K / 128;
+    auto decode = [&](int w, int& m0, int& n0) {
+        const int q = total >> 3, r = total & 7, xcd = w & 7;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
+        m0 = (wg / tiles_n) * BMT;
+        n0 = (wg % tiles_n) * BN;
+    };
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)p.M - 1) * p.lda + p.K), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)p.N - 1) * p.ldb + p.K), 0x00020000);
+    const int va = (lane >> 3) * p.lda + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    const int vb = (lane >> 3) * p.ldb + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
+    auto stage = [&](int m0, int n0, int t) {
+        int kc = t + m0 / BMT + n0 / BN;
+        kc = p.rotate ? kc % nk : t;
+        stage_tile_bytes<MI>(ra, va, p.lda, m0, kc * 128, smem, wave_u);
+        stage_tile_bytes<4>(rb, vb, p.ldb, n0, kc * 128, smem + A_BYTES, wave_u);
+    };
+    const unsigned char* ta = smem;
+    const unsigned char* tb = smem + A_BYTES;
+    float* ep = (float*)(smem + STG) + wave * (16 * 64);
+    const float alpha = p.a_scale_inv[0] * p.b_scale_inv[0];
+    int w = blockIdx.x, m0, n0;
+    decode(w, m0, n0);
+    stage(m0, n0, 0);
+    bool prev_full = false;
+    for (;;) {
+        const int wnext = w + (int)gridDim.x;
+        const bool has_next = wnext < total;
+        int m1 = 0, n1 = 0;
+        if (has_next) decode(wnext, m1, n1);
+        f32x4 acc[MI][4];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // the stores of the previous (full) tile's epilogue are younger than this tile's first k-stage: a LOWER bound of their count
+        // is all the wait needs (the e4m3 copy of the GELU output adds stores and an atomic that are not counted)
+        constexpr int SE = pers_epi_stores<EPI, MI>();
+        if (prev_full) G8_WAIT_VM(SE);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        for (int t = 0; t < nk; ++t) {
+            i32x8 af[MI], bfr[4];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af[i] = read_frag_fp8(ta, wm * (16 * MI) + 16 * i, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bfr[i] = read_frag_fp8(tb, wn * 64 + 16 * i, lane);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // every wave holds k-stage t in registers: the LDS stage is free
+            if (t + 1 < nk) stage(m0, n0, t + 1);
+            else if (has_next) stage(m1, n1, 0);   // the next tile's first k-stage flies under this tile's epilogue
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+            if (t + 1 < nk) {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();      // k-stage t+1 landed and is visible to every wave
+            }
+        }
+        prev_full = (m0 + BMT <= p.M) && (n0 + BN <= p.N);
+        epilogue<EPI, MI, MI, true>(p, acc, ep, m0 + wm * (16 * MI), n0 + wn * 64, prev_full, lane, false, alpha);
+        if (!has_next) break;
+        w = wnext;
+        m0 = m1;
+        n0 = n1;
+    }
+}
+
 #include "gemm8.h"
 #include "gemm_k2.h"
 #include "gemm_r3.h"
@@ -1126,7 +1239,10 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
     if (op == MOFO_GEMM_NT_FP8) {
         if (a->K % 128 || a->lda % 16 || a->ldb % 16) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: K must be a multiple of 128, lda / ldb of 16");
         if (!a->a_scale_inv || !a->b_scale_inv) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm NT_FP8: needs the device scalars a_scale_inv, b_scale_inv");
-        if (epi != MOFO_EPI_BF16 && epi != MOFO_EPI_BIAS_GELU) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: epilogues BF16 and BIAS_GELU only");
+        if (epi != MOFO_EPI_BF16 && epi != MOFO_EPI_BIAS_GELU && epi != MOFO_EPI_RESID_F32 && epi != MOFO_EPI_RESID_BF16)
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: epilogues BF16, BIAS_GELU, RESID_F32, RESID_BF16 only");
+        if (a->C8 && (epi != MOFO_EPI_BIAS_GELU || !a->q_scale || !a->q_amax || a->ldc8 % 8))
+            MOFO_FAIL(MOFO_EINVAL, "mofo_gemm NT_FP8: the e4m3 activation copy (C8) rides on BIAS_GELU and needs q_scale, q_amax, ldc8 a multiple of 8");
         if ((a->splits > 1) || a->accumulate) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: no split-K / accumulate");
     }
     if (op == MOFO_GEMM_NN && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NN: K=%d must be a multiple of 64", a->K);
@@ -1170,6 +1286,10 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
     p.atomic = (splits > 1 || a->accumulate) ? 1 : 0;
     p.a_scale_inv = a->a_scale_inv;
     p.b_scale_inv = a->b_scale_inv;
+    p.C8 = op == MOFO_GEMM_NT_FP8 ? (unsigned char*)a->C8 : nullptr;
+    p.ldc8 = a->ldc8;
+    p.q_scale = a->q_scale;
+    p.q_amax = a->q_amax;
     p.colsum = a->colsum;
     p.colsum_skip_lo = a->colsum_skip_lo;
     p.colsum_skip_hi = a->colsum_skip_hi;
@@ -1178,7 +1298,7 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
         // share an A panel, long epilogue) 126 -> 106 us (decoder), 38.0 -> 37.2 (encoder); neutral for the other wide-N
         // GEMMs; 5-10 % SLOWER for the N = 384 ones (3 n-tiles: little to de-duplicate, and the block's own row panel is no
         // longer streamed in order).  (The MOFO_GEMM_ROTATE / _ROTATE_TILE overrides were retired in round 5.)
-        p.rotate = (op == MOFO_GEMM_NT && epi == MOFO_EPI_BIAS_GELU);
+        p.rotate = ((op == MOFO_GEMM_NT || op == MOFO_GEMM_NT_FP8) && epi == MOFO_EPI_BIAS_GELU);
         p.rotate_tile = 1;
         p.aux_nt = (long long)a->M * a->N * 2 >= (96LL << 20);
     }
@@ -1213,13 +1333,27 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
     } else if (op == MOFO_GEMM_NT_FP8 && g.count == 1) {
         const GemmP& p = g.p[0];
         const int total = g.start[1];
-        if (epi == MOFO_EPI_BF16) {
-            if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 2>), dim3(total), dim3(256), 0, s, p, total);
-            else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 4>), dim3(total), dim3(256), 0, s, p, total);
-        } else {
-            if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 2>), dim3(total), dim3(256), 0, s, p, total);
-            else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 4>), dim3(total), dim3(256), 0, s, p, total);
-        }
+        const dim3 pgrid(total < 768 ? total : 768), block(256);
+#define GO8(E)                                                                                                           \
+    do {                                                                                                                 \
+        if (mi == 2) hipLaunchKernelGGL((gemm_fp8_persistent_kernel<E, 2>), pgrid, block, 0, s, p, total);               \
+        else hipLaunchKernelGGL((gemm_fp8_persistent_kernel<E, 4>), pgrid, block, 0, s, p, total);                       \
+    } while (0)
+        const char* ef = getenv("MOFO_FP8_FORM");     // 0: the one-tile-per-block two-stage kernel of rounds 2-4 (A/B tools)
+        if (ef && atoi(ef) == 0 && (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU)) {
+            if (epi == MOFO_EPI_BF16) {
+                if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 2>), dim3(total), dim3(256), 0, s, p, total);
+                else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 4>), dim3(total), dim3(256), 0, s, p, total);
+            } else {
+                if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 2>), dim3(total), dim3(256), 0, s, p, total);
+                else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 4>), dim3(total), dim3(256), 0, s, p, total);
+            }
+        } else if (epi == MOFO_EPI_BF16) GO8(MOFO_EPI_BF16);
+        else if (epi == MOFO_EPI_BIAS_GELU) GO8(MOFO_EPI_BIAS_GELU);
+        else if (epi == MOFO_EPI_RESID_F32) GO8(MOFO_EPI_RESID_F32);
+        else if (epi == MOFO_EPI_RESID_BF16) GO8(MOFO_EPI_RESID_BF16);
+        else MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: epilogue %d is not built", epi);
+#undef GO8
         ROUTE(ROUTE_FP8);
         MOFO_CHECK_LAUNCH("mofo_gemm(fp8)");
         return MOFO_OK;
@@ -1387,7 +1521,7 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
             mi8 = e8 ? atoi(e8) : -1;
         }
         if (mi != 2 && mi8 != 0 && count == 1 && a[0].splits <= 1 && !a[0].accumulate && a[0].epilogue != MOFO_EPI_POS_F32 &&
-            a[0].epilogue != MOFO_EPI_POS_BF16 && a[0].op != MOFO_GEMM_NT_FP8) {
+            a[0].epilogue != MOFO_EPI_POS_BF16 && a[0].op != MOFO_GEMM_NT_FP8) {   // (e4m3: 256-row tiles measured slower on 7 of 8 ViT-L shapes, profiles/r05_gemm_fp8_ab.txt)
             const long long t256 = (long long)ceil_div(a[0].M, 256) * ceil_div(a[0].N, BN);
             const double eff4 = (double)t128 / (double)(ceil_div((int)t128, 768) * 768);
             const double eff8 = (double)t256 / (double)(ceil_div((int)t256, 512) * 512);

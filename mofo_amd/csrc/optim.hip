@@ -37,13 +37,23 @@ __global__ __launch_bounds__(1024) void norm_final_kernel(const float* __restric
     }
 }
 
+// Q8 (mofo_adamw_q8, BASELINE configs[4]): the update also writes the OCP e4m3 shadow of the GEMM weights the fp8 forward reads -- the
+// pass that has the new weight in registers anyway (a separate amax + quantise pair over the bf16 shadow cost 0.56 ms per ViT-L step).
+// Per-tensor DELAYED scale: chunk_seg names each 1024-element chunk's weight matrix (-1: not an fp8 operand), w_scale[seg] = 448 / (the
+// maximum this matrix had after the PREVIOUS update) (mofo_fp8_roll_scales), and the maximum of the new values goes to w_amax[seg]
+// for the next one.  A weight moves by ~lr per step, so the rare value beyond the old maximum saturates at 448 = its rounding error.
+// A block walks a contiguous run of chunks here (the plain form strides over the grid) and keeps a running maximum while the matrix
+// stays the same: one atomic per (block, matrix), as quant.hip's amax pass.
+template <bool Q8>
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, bf16_t* __restrict__ pb, long long n4,
                                                     const uint8_t* __restrict__ chunk_group, float lr0, float wd0, float lr1,
                                                     float wd1, float b1, float b2, float eps, float inv_bc1, float inv_sqrt_bc2,
                                                     const float* __restrict__ grad_norm, float max_norm, float grad_mult,
                                                     float* __restrict__ sumsq_partial, const float* __restrict__ gate_finite,
-                                                    const int* __restrict__ gate_zero, const float* __restrict__ gate_one) {
+                                                    const int* __restrict__ gate_zero, const float* __restrict__ gate_one,
+                                                    const short* __restrict__ chunk_seg, const float* __restrict__ w_scale,
+                                                    float* __restrict__ w_amax, uint8_t* __restrict__ p8) {
     __shared__ float red[4];
     // Device-side gate (mofo_adamw_gated): the reference stops BEFORE backward on a non-finite loss
     // (engine_for_pretraining.py:168-170); here the update is already enqueued when the host reads the loss, so the kernel
@@ -64,7 +74,26 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         const float coef = max_norm / (grad_norm[0] * grad_mult + 1e-6f);
         gm *= fminf(coef, 1.0f);
     }
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+    long long i0 = (long long)blockIdx.x * 256 + threadIdx.x, iend = n4, istep = (long long)gridDim.x * 256;
+    int cur = -1;                       // Q8: the weight matrix of the chunks walked so far, its scale and running maximum
+    float qsc = 0.f, qmax = 0.f;
+    __shared__ float qred[4];
+    auto qflush = [&]() {               // block-uniform
+        if (cur < 0) return;
+        const float wm = wave_max(qmax);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) qred[threadIdx.x >> 6] = wm;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicMax((unsigned*)(w_amax + cur), __float_as_uint(fmaxf(fmaxf(qred[0], qred[1]), fmaxf(qred[2], qred[3]))));
+    };
+    if constexpr (Q8) {
+        const long long nch = n4 >> 8, per = (nch + gridDim.x - 1) / gridDim.x;
+        const long long c0 = (long long)blockIdx.x * per, c1 = c0 + per < nch ? c0 + per : nch;
+        i0 = c0 * 256 + threadIdx.x;
+        iend = c1 * 256;
+        istep = 256;
+    }
+    for (long long i = i0; i < iend; i += istep) {
 #ifndef MOFO_ADAMW_NT
 #define MOFO_ADAMW_NT 1
 #endif
@@ -97,8 +126,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
         if (pb) {
             u32x2 pk = {pack_bf16x2(pv[0], pv[1]), pack_bf16x2(pv[2], pv[3])};
             ((u32x2*)pb)[i] = pk;
+            if constexpr (Q8) {
+                const int seg = chunk_seg[i >> 8];      // block-uniform: one chunk per block and iteration
+                if (seg != cur) {
+                    qflush();
+                    cur = seg;
+                    qmax = 0.f;
+                    qsc = seg >= 0 ? w_scale[seg] : 0.f;
+                }
+                if (seg >= 0) {
+                    // quantise what the bf16 consumers see (the rounded values), as the standalone quantiser does
+                    const float q0 = bf16lo_to_f32(pk[0]), q1 = bf16hi_to_f32(pk[0]), q2 = bf16lo_to_f32(pk[1]), q3 = bf16hi_to_f32(pk[1]);
+                    qmax = fmaxf(qmax, fmaxf(fmaxf(fabsf(q0), fabsf(q1)), fmaxf(fabsf(q2), fabsf(q3))));
+                    ((uint32_t*)p8)[i] = pack4_e4m3(q0 * qsc, q1 * qsc, q2 * qsc, q3 * qsc);
+                }
+            }
         }
     }
+    if constexpr (Q8) qflush();
     if (sumsq_partial) {                // wave-uniform
         ssq = wave_sum(ssq);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = ssq;
@@ -140,10 +185,39 @@ extern "C" int mofo_sumsq(const float* g, long long n, float* partial, float* ou
     return MOFO_OK;
 }
 
-extern "C" int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
-                                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
-                                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
-                                const float* gate_finite, const int* gate_zero, const float* gate_one, void* stream) {
+namespace {
+// before a step's first mofo_adamw_q8: scale[i] = 448 / amax[i], scale_inv[i] = amax[i] / 448 (what the GEMMs multiply by once the
+// update has re-written the e4m3 shadow with this scale), amax[i] = 0 for the update to collect the next maximum.  A matrix whose
+// maximum is 0 (a declined update wrote nothing since the last roll; an all-zero matrix) keeps its scale.
+__global__ void roll_scales_kernel(float* __restrict__ amax, float* __restrict__ scale, float* __restrict__ scale_inv, int n,
+                                   const float* __restrict__ gate_finite, const int* __restrict__ gate_zero, const float* __restrict__ gate_one) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    // the gate of the update that follows (adamw_kernel): a declined update leaves the e4m3 shadow as it is, so its scales stay too
+    if ((gate_finite && !(fabsf(gate_finite[0]) <= 3.402823466e38f)) || (gate_zero && gate_zero[0] != 0) || (gate_one && gate_one[0] != 1.0f)) return;
+    const float a = amax[i];
+    if (a > 0.f && a < 3.0e38f) {
+        scale[i] = 448.0f / a;
+        scale_inv[i] = a / 448.0f;
+    }
+    amax[i] = 0.f;
+}
+}  // namespace
+
+extern "C" int mofo_fp8_roll_scales(float* amax, float* scale, float* scale_inv, int n, const float* gate_finite, const int* gate_zero,
+                                    const float* gate_one, void* stream) {
+    if (!amax || !scale || !scale_inv || n <= 0) MOFO_FAIL(MOFO_EINVAL, "mofo_fp8_roll_scales: bad arguments");
+    hipLaunchKernelGGL(roll_scales_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, amax, scale, scale_inv, n, gate_finite, gate_zero,
+                       gate_one);
+    MOFO_CHECK_LAUNCH("mofo_fp8_roll_scales");
+    return MOFO_OK;
+}
+
+static int adamw_launch(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                        float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                        const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                        const float* gate_finite, const int* gate_zero, const float* gate_one, const short* chunk_seg,
+                        const float* w_scale, float* w_amax, void* p_e4m3, void* stream) {
     if (!p || !g || !m || !v || !chunk_group) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: null pointer");
     if (n <= 0 || n % 1024) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_adamw: n must be a positive multiple of 1024");
     if (step < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw: step starts at 1");
@@ -151,15 +225,40 @@ extern "C" int mofo_adamw_gated(float* p, const float* g, float* m, float* v, vo
     const double bc2 = 1.0 - pow((double)beta2, (double)step);
     const float inv_bc1 = (float)(1.0 / bc1);
     const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
-                       chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
-                       norm_partial, gate_finite, gate_zero, gate_one);
+    if (p_e4m3) {
+        if (!p_bf16 || !chunk_seg || !w_scale || !w_amax) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw_q8: the e4m3 shadow needs the bf16 shadow, chunk_seg, w_scale, w_amax");
+        hipLaunchKernelGGL(adamw_kernel<true>, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
+                           chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
+                           norm_partial, gate_finite, gate_zero, gate_one, chunk_seg, w_scale, w_amax, (uint8_t*)p_e4m3);
+    } else {
+        hipLaunchKernelGGL(adamw_kernel<false>, dim3(stream_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, (bf16_t*)p_bf16, n / 4,
+                           chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, inv_bc1, inv_sqrt_bc2, grad_norm, max_norm, grad_mult,
+                           norm_partial, gate_finite, gate_zero, gate_one, nullptr, nullptr, nullptr, nullptr);
+    }
     MOFO_CHECK_LAUNCH("mofo_adamw");
     if (norm_partial && norm_out) {     // global gradient L2 norm as a by-product of the pass that reads the gradients anyway
         hipLaunchKernelGGL(norm_final_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, (const float*)norm_partial, stream_blocks(n / 4), norm_out);
         MOFO_CHECK_LAUNCH("mofo_adamw(norm)");
     }
     return MOFO_OK;
+}
+
+extern "C" int mofo_adamw_gated(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                                float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                                const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                                const float* gate_finite, const int* gate_zero, const float* gate_one, void* stream) {
+    return adamw_launch(p, g, m, v, p_bf16, n, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm, max_norm, grad_mult, norm_partial,
+                        norm_out, gate_finite, gate_zero, gate_one, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int mofo_adamw_q8(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,
+                             float lr0, float wd0, float lr1, float wd1, float beta1, float beta2, float eps, int step,
+                             const float* grad_norm, float max_norm, float grad_mult, float* norm_partial, float* norm_out,
+                             const float* gate_finite, const int* gate_zero, const float* gate_one, const short* chunk_seg,
+                             const float* w_scale, float* w_amax, void* p_e4m3, void* stream) {
+    if (!p_e4m3) MOFO_FAIL(MOFO_EINVAL, "mofo_adamw_q8: null e4m3 shadow");
+    return adamw_launch(p, g, m, v, p_bf16, n, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm, max_norm, grad_mult, norm_partial,
+                        norm_out, gate_finite, gate_zero, gate_one, chunk_seg, w_scale, w_amax, p_e4m3, stream);
 }
 
 extern "C" int mofo_adamw(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const uint8_t* chunk_group,

@@ -12,16 +12,6 @@ namespace {
 
 constexpr float E4M3_MAX = 448.0f;
 
-__device__ __forceinline__ uint32_t pack4_e4m3(float a, float b, float c, float d) {
-    a = __builtin_amdgcn_fmed3f(a, -E4M3_MAX, E4M3_MAX);
-    b = __builtin_amdgcn_fmed3f(b, -E4M3_MAX, E4M3_MAX);
-    c = __builtin_amdgcn_fmed3f(c, -E4M3_MAX, E4M3_MAX);
-    d = __builtin_amdgcn_fmed3f(d, -E4M3_MAX, E4M3_MAX);
-    int r = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    r = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, r, true);
-    return (uint32_t)r;
-}
-
 // Each block walks a contiguous RUN of 1024-element chunks and keeps a running |x| max while the segment stays the same: one
 // atomicMax per (block, segment) instead of one per chunk (318 M parameters = 310 k chunks: at one atomic per chunk the same
 // few addresses took 1.5 ms; non-negative floats order as uints).

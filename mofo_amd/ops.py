@@ -144,7 +144,8 @@ def gemm_grouped_plan(op, epi, problems):
 
 
 def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, pos=None, row_idx=None, rows_in=0, rows_out=0,
-               row_off=0, splits=1, accumulate=False, colsum=None, colsum_skip=(0, 0), a_scale_inv=None, b_scale_inv=None):
+               row_off=0, splits=1, accumulate=False, colsum=None, colsum_skip=(0, 0), a_scale_inv=None, b_scale_inv=None,
+               C8=None, q_scale=None, q_amax=None):
     if op == GEMM_NT_FP8:
         _chk(A, F8, "A", 2), _chk(B, F8, "B", 2), _chk(a_scale_inv, F32, "a_scale_inv"), _chk(b_scale_inv, F32, "b_scale_inv")
     else:
@@ -180,6 +181,12 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
         _chk(C2, BF16, "C2", 2)
         if tuple(C2.shape) != (M, N):
             raise ValueError("C2 shape")
+    if C8 is not None:       # e4m3 copy of the activation (the A operand of an fp8 fc2), delayed scale, amax stripes
+        if op != GEMM_NT_FP8 or epi != EPI_BIAS_GELU:
+            raise ValueError("C8 rides on NT_FP8 + BIAS_GELU")
+        _chk(C8, F8, "C8", 2), _chk(q_scale, F32, "q_scale"), _chk(q_amax, F32, "q_amax")
+        if tuple(C8.shape) != (M, N) or q_amax.numel() != FP8_AMAX_STRIPES or not q_amax.is_contiguous():
+            raise ValueError("C8 must be [M, N]; q_amax the %d stripes of one site" % FP8_AMAX_STRIPES)
     rmapped = epi in (EPI_RESID_F32, EPI_RESID_BF16) and rows_in > 0     # residual rows (m / rows_in) * rows_out + row_off + m % rows_in
     rrows = ((M // rows_in - 1) * rows_out + row_off + rows_in) if rmapped else M
     if rmapped and (M % rows_in or row_off < 0 or row_off + rows_in > rows_out):
@@ -201,12 +208,13 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
                  ldr=_ld(resid) if resid is not None else 0, aux=_p(aux), ldaux=_ld(aux) if aux is not None else 0,
                  pos=_p(pos), ldpos=_ld(pos) if pos is not None else 0, row_idx=_p(row_idx), rows_in=rows_in,
                  rows_out=rows_out, row_off=row_off, splits=splits, accumulate=1 if accumulate else 0, colsum=_p(colsum),
-                 colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1], a_scale_inv=_p(a_scale_inv), b_scale_inv=_p(b_scale_inv))
+                 colsum_skip_lo=colsum_skip[0], colsum_skip_hi=colsum_skip[1], a_scale_inv=_p(a_scale_inv), b_scale_inv=_p(b_scale_inv),
+                 C8=_p(C8), ldc8=_ld(C8) if C8 is not None else 0, q_scale=_p(q_scale), q_amax=_p(q_amax))
     # algorithmic HBM bytes of the launch: every operand read once, every output written once (bench.py's roofline block)
     esz = 4.0 if out_dtype == F32 else 2.0
     nbytes = A.element_size() * (M * K + N * K) + esz * M * N
     if epi == EPI_BIAS_GELU:
-        nbytes += 2.0 * M * N
+        nbytes += (3.0 if C8 is not None else 2.0) * M * N
     elif epi == EPI_RESID_F32:
         nbytes += resid.element_size() * M * N
     elif epi in (EPI_DGELU_BF16, EPI_RESID_BF16):
@@ -304,6 +312,16 @@ def fp8_update_scales(amax, scales, margin=1.5):
     _run("mofo_fp8_update_scales", ("fp8_scales",), 12.0 * n, _p(amax), _p(scales), n, float(margin))
 
 
+def fp8_roll_scales(amax, scale, scale_inv, gate_finite=None, gate_zero=None, gate_one=None):
+    """weights' delayed scaling, once per step before the first adamw(q8=...) launch: scale = 448 / amax, scale_inv = amax / 448, amax = 0;
+    the gate words of that update (a declined update changes neither the e4m3 shadow nor its scales)"""
+    _chk(amax, F32, "amax", 1), _chk(scale, F32, "scale", 1), _chk(scale_inv, F32, "scale_inv", 1)
+    n = amax.numel()
+    if scale.numel() != n or scale_inv.numel() != n:
+        raise ValueError("fp8_roll_scales: three arrays of one length")
+    _run("mofo_fp8_roll_scales", ("fp8_scales",), 16.0 * n, _p(amax), _p(scale), _p(scale_inv), n, _p(gate_finite), _p(gate_zero), _p(gate_one))
+
+
 def layernorm_bwd_blocks(M):
     """block rows a LayerNorm backward over M rows leaves in its partial_ws"""
     return _lib.load().mofo_layernorm_bwd_blocks(int(M))
@@ -382,13 +400,22 @@ def layernorm_bwd_finalize(items):
     _run("mofo_layernorm_bwd_finalize", ("ln_bwd_fin",), sum(8.0 * t[1] * t[2] for t in items), *args, n)
 
 
-def attention_fwd(qkv, B, N, H, scale, out, lse2, q_begin=0):
-    """``q_begin`` > 0: only the query rows q_begin .. N - 1 of every clip; ``out`` is then the compact [B * (N - q_begin), H * 64]"""
+def attention_fwd(qkv, B, N, H, scale, out, lse2, q_begin=0, out8=None, q_scale=None, q_amax=None):
+    """``q_begin`` > 0: only the query rows q_begin .. N - 1 of every clip; ``out`` is then the compact [B * (N - q_begin), H * 64].
+    ``out8`` (e4m3, shape of ``out``) + ``q_scale`` (f32 [1]) + ``q_amax`` (the stripes of one site): the rows also go out as
+    sat(O * q_scale[0]) for an fp8 proj GEMM (mofo_attention_fwd_q8)"""
     _chk(qkv, BF16, "qkv", 2), _chk(out, BF16, "out", 2), _chk(lse2, F32, "lse2")
     if not 0 <= q_begin < N:
         raise ValueError("attention_fwd: q_begin out of range")
     if qkv.shape != (B * N, 3 * H * 64) or out.shape != (B * (N - q_begin), H * 64) or lse2.numel() != B * H * N:
         raise ValueError("attention_fwd: shape mismatch")
+    if out8 is not None:
+        _chk(out8, F8, "out8", 2), _chk(q_scale, F32, "q_scale"), _chk(q_amax, F32, "q_amax")
+        if out8.shape != out.shape or q_amax.numel() != FP8_AMAX_STRIPES or not q_amax.is_contiguous():
+            raise ValueError("attention_fwd: out8 must have out's shape, q_amax the %d stripes of one site" % FP8_AMAX_STRIPES)
+        _run("mofo_attention_fwd_q8", ("attn_fwd",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, q_begin, _p(out), _ld(out),
+             _p(lse2), _p(out8), _ld(out8), _p(q_scale), _p(q_amax))
+        return out
     _run("mofo_attention_fwd_range", ("attn_fwd",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, q_begin, _p(out), _ld(out),
          _p(lse2))
     return out
@@ -673,8 +700,10 @@ def norm_finalize(partial, count, out_norm):
 
 
 def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps, step, grad_norm=None, max_norm=0.0, grad_mult=1.0,
-          norm_partial=None, norm_out=None, gate_finite=None, gate_zero=None, gate_one=None):
-    """``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out.
+          norm_partial=None, norm_out=None, gate_finite=None, gate_zero=None, gate_one=None, q8=None):
+    """``q8`` = (chunk_seg int16 [n / 1024], w_scale f32 [nseg], w_amax f32 [nseg], p_e4m3 [n]): the update also writes the e4m3
+    shadow of the fp8 forward's weights with the delayed per-matrix scale (mofo_adamw_q8; ``fp8_roll_scales`` once per step first).
+    ``norm_partial`` (f32 [>= 2048]) + ``norm_out`` (f32 [1]): also leave the global L2 norm of ``g`` in norm_out.
     ``gate_finite`` (f32 [1]) / ``gate_zero`` (i32 [1]) / ``gate_one`` (f32 [1]): device words the kernel checks before it touches
     anything -- the update is skipped unless the first is finite, the second 0 and the third 1.0 (mofo_adamw_gated)."""
     for t, n in ((p, "p"), (g, "g"), (m, "m"), (v, "v")):
@@ -701,6 +730,15 @@ def adamw(p, g, m, v, p_bf16, chunk_group, lr0, wd0, lr1, wd1, beta1, beta2, eps
         _chk(gate_zero, I32, "gate_zero")
     if gate_one is not None:
         _chk(gate_one, F32, "gate_one")
+    if q8 is not None:
+        chunk_seg, w_scale, w_amax, p8 = q8
+        _chk(w_scale, F32, "w_scale", 1), _chk(w_amax, F32, "w_amax", 1), _chk(p8, F8, "p_e4m3", 1)
+        if chunk_seg is None or chunk_seg.dtype != torch.int16 or not chunk_seg.is_cuda or chunk_seg.numel() * 1024 != n or p8.numel() != n or p_bf16 is None:
+            raise ValueError("adamw q8: chunk_seg int16 [n / 1024] on the GPU, p_e4m3 [n], and the bf16 shadow")
+        _run("mofo_adamw_q8", ("adamw",), 31.0 * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
+             lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out),
+             _p(gate_finite), _p(gate_zero), _p(gate_one), _p(chunk_seg), _p(w_scale), _p(w_amax), _p(p8))
+        return
     _run("mofo_adamw_gated", ("adamw",), (28.0 + (2.0 if p_bf16 is not None else 0.0)) * n, _p(p), _p(g), _p(m), _p(v), _p(p_bf16), n, _p(chunk_group),
          lr0, wd0, lr1, wd1, beta1, beta2, eps, step, _p(grad_norm), max_norm, grad_mult, _p(norm_partial), _p(norm_out),
          _p(gate_finite), _p(gate_zero), _p(gate_one))

@@ -126,6 +126,12 @@ class FusedAdamW(torch.optim.Optimizer):
         gf, gz, go = getattr(rt, "step_gate", None) or (None, None, None)
         rt.step_gate = None
         gate = dict(gate_finite=gf, gate_zero=gz, gate_one=go)
+        # MOFO_FP8=1: this pass also writes the e4m3 shadow of the fp8 forward's weights (delayed per-matrix scale = 448 / the maximum the
+        # PREVIOUS update left; ops.fp8_roll_scales).  Only while that shadow is current -- after a load_state_dict / a foreign write the
+        # next forward re-quantises from the bf16 shadow with exact scales and this path resumes with the update after it.
+        q8 = hasattr(st, "shadow8") and st.shadow8_current()
+        if q8:
+            ops.fp8_roll_scales(st._amax_ws, st.w_scale, st.w_scale_inv, **gate)
         if ranges is not None:
             if max_norm or grad_norm is not None:
                 raise ValueError("range-by-range update is for the un-clipped step")
@@ -150,7 +156,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 nb = ops.adamw_blocks(hi - lo)
                 ops.adamw(st.params[lo:hi], st.grads[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], st.shadow[lo:hi],
                           st.chunk_group[lo // 1024:hi // 1024], *hyper, norm_partial=self._range_partial[slot:slot + nb] if norm_out is not None else None,
-                          **gate)
+                          q8=st.q8_args(lo, hi) if q8 else None, **gate)
                 slot += nb
                 covered += hi - lo
             if measure:
@@ -161,8 +167,10 @@ class FusedAdamW(torch.optim.Optimizer):
                 ops.norm_finalize(self._range_partial, slot, norm_out)
         else:
             ops.adamw(st.params, st.grads, self.exp_avg, self.exp_avg_sq, st.shadow, st.chunk_group, *hyper, grad_norm=grad_norm,
-                      max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out, **gate)
+                      max_norm=float(max_norm) if max_norm else 0.0, norm_partial=partial, norm_out=norm_out, q8=st.q8_args() if q8 else None, **gate)
         st.mark_shadow_fresh()
+        if q8:
+            st.mark_shadow8_fresh()
 
     # checkpoint.  Written in torch.optim.AdamW's own state_dict layout -- state[i] = {'step','exp_avg','exp_avg_sq'} with i
     # counting parameters group by group, param_groups[g]['params'] = index lists -- i.e. exactly what the reference's

@@ -209,6 +209,7 @@ class FlatStore:
         self.chunk_seg = torch.from_numpy(seg).to(self.device)
         self.shadow8 = torch.zeros(self.total, dtype=torch.float8_e4m3fn, device=self.device)
         self.w_scale_inv = torch.ones(len(self.fp8_names), dtype=F32, device=self.device)
+        self.w_scale = torch.ones(len(self.fp8_names), dtype=F32, device=self.device)   # what the fused AdamW quantises with (delayed)
         self._amax_ws = torch.zeros(len(self.fp8_names), dtype=F32, device=self.device)
         self._shadow8_epoch = -1
 
@@ -220,7 +221,21 @@ class FlatStore:
         i = self.fp8_names.index(name)
         return self.w_scale_inv[i:i + 1]
 
+    def shadow8_current(self) -> bool:
+        """the e4m3 shadow (and the per-matrix maxima in _amax_ws) belong to the current bf16 shadow"""
+        return self._shadow8_epoch == self.shadow_epoch
+
+    def q8_args(self, lo=0, hi=None):
+        """what ops.adamw(q8=...) takes for the flat range [lo, hi): the fused update then writes the e4m3 shadow itself"""
+        hi = self.total if hi is None else hi
+        return (self.chunk_seg[lo // CHUNK:hi // CHUNK], self.w_scale, self._amax_ws, self.shadow8[lo:hi])
+
+    def mark_shadow8_fresh(self):
+        self._shadow8_epoch = self.shadow_epoch
+
     def refresh_shadow8(self):
+        """exact per-matrix scales from the bf16 shadow (two launches): the first forward, and whenever somebody other than the fused
+        AdamW changed the weights (load_state_dict, a foreign optimizer); the fused AdamW keeps the e4m3 shadow current itself"""
         if self._shadow8_epoch != self.shadow_epoch:
             ops.fp8_quantize_segments(self.shadow, self.chunk_seg, len(self.fp8_names), self._amax_ws, self.shadow8, self.w_scale_inv)
             self._shadow8_epoch = self.shadow_epoch
@@ -349,27 +364,30 @@ class PretrainRuntime:
         # The encoder's stream stays f32 as in the reference: bf16 passed the parity gates and did not move the step (11.90 / 11.92 vs
         # 11.96 / 11.87 ms, round 2: its kernels are latency-bound at 5 120 token rows); the switch was retired in round 5.
         self.enc_resid = F32
-        # MOFO_FP8=1: the forward Linears fed by a LayerNorm (qkv, fc1) run on OCP e4m3 operands with the block-scaled MFMA
-        # (2x the bf16 MFMA rate; BASELINE configs[4] "fp8 MFMA attention/MLP").  Per-tensor scales: weights from their amax
-        # every time the shadow changes, activations with delayed scaling (a LayerNorm's scale comes from the amax it saw in
-        # the previous forward; the first forward of a runtime is run once more to calibrate).  Backward stays bf16.
+        # MOFO_FP8=1 (BASELINE configs[4] "fp8 MFMA attention/MLP"): the four forward Linears of every block (qkv, proj, fc1, fc2) run on
+        # OCP e4m3 operands with the block-scaled MFMA (2x the bf16 MFMA rate).  Per-tensor scales.  Weights: an e4m3 shadow written by
+        # the fused AdamW with a delayed per-matrix scale (exact scales from the bf16 shadow before the first step / after a load).
+        # Activations, delayed scaling per site: the e4m3 copies are written by the producing kernels -- LayerNorm 1 / 2 (qkv, fc1),
+        # the attention forward (proj), fc1's GELU epilogue (fc2) -- with the scale from the amax the site saw in the previous forward;
+        # the first forward of a runtime is run once more to calibrate.  The bf16 copies stay (the backward reads them): backward is bf16.
         self.fp8 = os.environ.get("MOFO_FP8", "0") == "1" and not forward_only and top and enc_prefix is not None and dec_prefix is not None
         if self.fp8:
             blocks = (self.encW if enc_prefix is not None else []) + (self.decW if dec_prefix is not None else [])
-            names = [n for W in blocks for n in (W.prefix + "attn.qkv.weight", W.prefix + "mlp.fc1.weight")
-                     if store.shape[n][1] % 128 == 0]
+            kinds = (("qkv8", "attn.qkv.weight"), ("proj8", "attn.proj.weight"), ("fc18", "mlp.fc1.weight"), ("fc28", "mlp.fc2.weight"))
+            names = [W.prefix + n for W in blocks for _, n in kinds if store.shape[W.prefix + n][1] % 128 == 0]
             self.fp8 = bool(names)
             if self.fp8:
                 store.enable_fp8(names)
                 for W in blocks:
-                    for attr, n in (("qkv8", W.prefix + "attn.qkv.weight"), ("fc18", W.prefix + "mlp.fc1.weight")):
+                    for attr, n in kinds:
+                        n = W.prefix + n
                         setattr(W, attr, store.b8view(n) if n in names else None)
                         setattr(W, attr + "_si", store.w_si(n) if n in names else None)
-                nsite = 2 * len(blocks)
+                nsite = 4 * len(blocks)       # per block: LayerNorm 1 out, attention out, LayerNorm 2 out, GELU out
                 self.act_scales = torch.tensor([[16.0, 1.0 / 16.0]] * nsite, dtype=F32, device=self.dev)
                 self.act_amax = torch.zeros(nsite, ops.FP8_AMAX_STRIPES, dtype=F32, device=self.dev)
                 for i, W in enumerate(blocks):
-                    W.site = 2 * i
+                    W.site = 4 * i
                 self._fp8_calibrated = False
         self._accumulate = False   # True when backward must ADD to existing gradients (no zero_grad since the last backward)
         self.side = torch.cuda.Stream(device=self.dev) if self.dev.type == "cuda" else None
@@ -432,7 +450,8 @@ class PretrainRuntime:
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
         f8 = torch.float8_e4m3fn
-        extra = dict(xln1_8=e(M, D, dt=f8), xln2_8=e(M, D, dt=f8)) if getattr(self, "fp8", False) and D % 128 == 0 else {}
+        extra = (dict(xln1_8=e(M, D, dt=f8), xln2_8=e(M, D, dt=f8), ao8=e(M, D, dt=f8), g8=e(M, hid, dt=f8))
+                 if getattr(self, "fp8", False) and D % 128 == 0 and hid % 128 == 0 else {})
         return NS(**extra, xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), ao=e(M, D), lse=e(B * H * n, dt=F32),
                   x_mid=e(M, D, dt=resid), xln2=e(M, D), mean2=e(M, dt=F32), rstd2=e(M, dt=F32), h1=e(M, hid), g=e(M, hid),
                   x_out=e(M, D, dt=resid))
@@ -444,7 +463,10 @@ class PretrainRuntime:
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
-        return NS(compact=True, xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), lse=e(B * H * n, dt=F32),
+        f8 = torch.float8_e4m3fn
+        extra = (dict(xln1_8=e(M, D, dt=f8), xln2_8=e(Mc, D, dt=f8), ao8=e(Mc, D, dt=f8), g8=e(Mc, hid, dt=f8))
+                 if getattr(self, "fp8", False) and D % 128 == 0 and hid % 128 == 0 else {})
+        return NS(**extra, compact=True, xln1=e(M, D), mean1=e(M, dt=F32), rstd1=e(M, dt=F32), qkv=e(M, 3 * D), lse=e(B * H * n, dt=F32),
                   ao=e(Mc, D), x_mid=e(Mc, D, dt=resid), xln2=e(Mc, D), mean2=e(Mc, dt=F32), rstd2=e(Mc, dt=F32), h1=e(Mc, hid), g=e(Mc, hid),
                   x_out=e(Mc, D, dt=resid))
 
@@ -499,7 +521,7 @@ class PretrainRuntime:
             # decoder.norm / head, modeling_pretrain.py:157; the visible tokens are the first n_vis rows of a clip, :259).  With the
             # full model (n_vis known here) that block works on the masked tokens only -- queries, proj, LayerNorm 2, MLP, their
             # backward and weight-gradient reductions: 10 % of its rows at mask 0.9.  MOFO_DEC_LAST_COMPACT=0 keeps all rows.
-            w.dec_compact = (n_vis is not None and 0 < n_vis < N and d.dec_depth >= 1 and not getattr(self, "fp8", False)
+            w.dec_compact = (n_vis is not None and 0 < n_vis < N and d.dec_depth >= 1
                              and os.environ.get("MOFO_DEC_LAST_COMPACT", "1") == "1")
             w.dec = [self._block_ws(Md, d.dec_dim, d.dec_heads, B, N, self.dec_resid) for _ in range(d.dec_depth - (1 if w.dec_compact else 0))]
             if w.dec_compact:
@@ -560,59 +582,54 @@ class PretrainRuntime:
             ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
 
     # ------------------------------------------------------------------ transformer block
-    def _block_fwd(self, W, L, x_in, B, n, H, share=None):
-        """``share`` (the first decoder block of the full model, see ``ws``): LayerNorm 1 and the qkv GEMM run once per cat row"""
+    def _block_fwd(self, W, L, x_in, B, n, H, share=None, qb=0):
+        """``share`` (the first decoder block of the full model, see ``ws``): LayerNorm 1 and the qkv GEMM run once per cat row.
+        ``qb`` > 0 (the LAST decoder block on the tokens that are read, rows qb .. n - 1 of every clip): keys / values from all rows, queries
+        and everything behind the attention from those rows only; the residual input is read through the GEMM's residual row map.
+        MOFO_FP8=1: the four Linears on e4m3 operands (the shared qkv of ``share`` stays bf16: 13 % of a block's qkv rows)."""
         eps, scale = self.d.eps, 64 ** -0.5
-        f8 = self.fp8 and getattr(W, "qkv8", None) is not None and hasattr(L, "xln1_8")
+        f8 = self.fp8 and getattr(W, "qkv8", None) is not None and hasattr(L, "ao8")
+        sc, am, st = (self.act_scales, self.act_amax, W.site) if f8 else (None, None, 0)
         if share is not None:
             Z = share
             ops.layernorm_fwd(Z.xcat, W.ln1w, W.ln1b, eps, Z.xln1, Z.mean1, Z.rstd1)
             ops.gemm(ops.GEMM_NT, ops.EPI_BF16, Z.xln1, W.qkv, Z.qkv, bias=W.qkvb)
             ops.dec0_gather(Z.qkv, Z.msk_idx, Z.N, L.qkv)
         elif f8:
-            sc, am = self.act_scales, self.act_amax
-            ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[W.site, 0:1], am[W.site])
-            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, L.xln1_8, W.qkv8, L.qkv, bias=W.qkvb, a_scale_inv=sc[W.site, 1:2], b_scale_inv=W.qkv8_si)
+            ops.layernorm_fwd_q(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1, L.xln1_8, sc[st, 0:1], am[st])
+            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, L.xln1_8, W.qkv8, L.qkv, bias=W.qkvb, a_scale_inv=sc[st, 1:2], b_scale_inv=W.qkv8_si)
         else:
             ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
             ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
-        ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse)
-        if L.x_mid.dtype == BF16:      # bf16 residual stream (decoder): the residual rides in the GEMM's `aux` operand
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.ao, W.proj, L.x_mid, bias=W.projb, aux=x_in)
-        else:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in)
+        rmap = dict(rows_in=n - qb, rows_out=n, row_off=qb) if qb else {}
         if f8:
-            ops.layernorm_fwd_q(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2, L.xln2_8, sc[W.site + 1, 0:1], am[W.site + 1])
-            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, L.xln2_8, W.fc18, L.h1, C2=L.g, bias=W.fc1b, a_scale_inv=sc[W.site + 1, 1:2],
-                     b_scale_inv=W.fc18_si)
+            ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse, q_begin=qb, out8=L.ao8, q_scale=sc[st + 1, 0:1], q_amax=am[st + 1])
+            A, Wp, op, kw = L.ao8, W.proj8, ops.GEMM_NT_FP8, dict(a_scale_inv=sc[st + 1, 1:2], b_scale_inv=W.proj8_si)
+        else:
+            ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse, q_begin=qb)
+            A, Wp, op, kw = L.ao, W.proj, ops.GEMM_NT, {}
+        if L.x_mid.dtype == BF16:      # bf16 residual stream (decoder): the residual rides in the GEMM's `aux` operand
+            ops.gemm(op, ops.EPI_RESID_BF16, A, Wp, L.x_mid, bias=W.projb, aux=x_in, **rmap, **kw)
+        else:
+            ops.gemm(op, ops.EPI_RESID_F32, A, Wp, L.x_mid, bias=W.projb, resid=x_in, **rmap, **kw)
+        if f8:
+            ops.layernorm_fwd_q(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2, L.xln2_8, sc[st + 2, 0:1], am[st + 2])
+            ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, L.xln2_8, W.fc18, L.h1, C2=L.g, bias=W.fc1b, a_scale_inv=sc[st + 2, 1:2],
+                     b_scale_inv=W.fc18_si, C8=L.g8, q_scale=sc[st + 3, 0:1], q_amax=am[st + 3])
+            A, Wf, kw = L.g8, W.fc28, dict(a_scale_inv=sc[st + 3, 1:2], b_scale_inv=W.fc28_si)
         else:
             ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
             ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
+            A, Wf, kw = L.g, W.fc2, {}
         if L.x_out.dtype == BF16:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.g, W.fc2, L.x_out, bias=W.fc2b, aux=L.x_mid)
+            ops.gemm(op, ops.EPI_RESID_BF16, A, Wf, L.x_out, bias=W.fc2b, aux=L.x_mid, **kw)
         else:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
+            ops.gemm(op, ops.EPI_RESID_F32, A, Wf, L.x_out, bias=W.fc2b, resid=L.x_mid, **kw)
         return L.x_out
 
     def _block_fwd_last(self, W, L, x_in, B, n, H, qb):
-        """the last decoder block on the tokens that are read (rows qb .. n - 1 of every clip): keys / values from all rows, queries and
-        everything behind the attention from those rows only; the residual input is read through the GEMM's residual row map"""
-        eps, scale = self.d.eps, 64 ** -0.5
-        ops.layernorm_fwd(x_in, W.ln1w, W.ln1b, eps, L.xln1, L.mean1, L.rstd1)
-        ops.gemm(ops.GEMM_NT, ops.EPI_BF16, L.xln1, W.qkv, L.qkv, bias=W.qkvb)
-        ops.attention_fwd(L.qkv, B, n, H, scale, L.ao, L.lse, q_begin=qb)
-        rmap = dict(rows_in=n - qb, rows_out=n, row_off=qb)
-        if L.x_mid.dtype == BF16:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.ao, W.proj, L.x_mid, bias=W.projb, aux=x_in, **rmap)
-        else:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.ao, W.proj, L.x_mid, bias=W.projb, resid=x_in, **rmap)
-        ops.layernorm_fwd(L.x_mid, W.ln2w, W.ln2b, eps, L.xln2, L.mean2, L.rstd2)
-        ops.gemm(ops.GEMM_NT, ops.EPI_BIAS_GELU, L.xln2, W.fc1, L.h1, C2=L.g, bias=W.fc1b)
-        if L.x_out.dtype == BF16:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_BF16, L.g, W.fc2, L.x_out, bias=W.fc2b, aux=L.x_mid)
-        else:
-            ops.gemm(ops.GEMM_NT, ops.EPI_RESID_F32, L.g, W.fc2, L.x_out, bias=W.fc2b, resid=L.x_mid)
-        return L.x_out
+        """the last decoder block on the tokens that are read (rows qb .. n - 1 of every clip), see ``_block_fwd``"""
+        return self._block_fwd(W, L, x_in, B, n, H, qb=qb)
 
     def _block_bwd_last(self, W, L, S, C, x_in, B, n, H, qb, flush=False):
         """backward of _block_fwd_last (always the first block of a decoder backward pass: scratch set 0, ring 0 -> 1).  The gradient

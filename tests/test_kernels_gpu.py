@@ -103,6 +103,31 @@ def test_gemm_nt_fp8(dev, M, N, K):
     C2 = torch.empty_like(C)
     ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, A8, W8, C, C2=C2, bias=bias, a_scale_inv=ai, b_scale_inv=wi)
     assert _rel(C, ref + bias) < 5e-3 and _rel(C2, torch.nn.functional.gelu(ref + bias)) < 8e-3
+    # the e4m3 copy of the activation (fc2's A operand) with a DELAYED scale that saturates part of it, and the launch's max|gelu|
+    g = torch.nn.functional.gelu(ref + bias)
+    qs = torch.tensor([448.0 / (0.5 * float(g.abs().max()))], dtype=F32, device=dev)
+    G8 = torch.zeros(M, N, dtype=F8, device=dev)
+    am = torch.zeros(ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
+    Cq, C2q = torch.empty_like(C), torch.empty_like(C)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BIAS_GELU, A8, W8, Cq, C2=C2q, bias=bias, a_scale_inv=ai, b_scale_inv=wi, C8=G8, q_scale=qs, q_amax=am)
+    assert torch.equal(Cq, C) and torch.equal(C2q, C2)
+    lim = 448.0 / float(qs)
+    assert _rel(G8.float() / qs, g.clamp(-lim, lim)) < 4e-2 and not torch.isnan(G8.float()).any()
+    assert float(am.max()) == pytest.approx(float(g.abs().max()), rel=1e-2)
+    # residual epilogues (proj / fc2), dense and through the residual row map of the last decoder block
+    R = _rand((M, N), dev, 6, 1.0, F32)
+    Cf = torch.empty(M, N, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_RESID_F32, A8, W8, Cf, bias=bias, resid=R, a_scale_inv=ai, b_scale_inv=wi)
+    assert _rel(Cf, ref + bias + R) < 1e-4
+    Rb = R.to(BF16)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_RESID_BF16, A8, W8, C, bias=bias, aux=Rb, a_scale_inv=ai, b_scale_inv=wi)
+    assert _rel(C, ref + bias + Rb.float()) < 5e-3
+    if M % 4 == 0:
+        rin, rout, roff = M // 4, M // 4 + 24, 24
+        Rbig = _rand((4 * rout, N), dev, 7, 1.0).contiguous()
+        want = ref + bias + Rbig.view(4, rout, N)[:, roff:roff + rin].reshape(M, N).float()
+        ops.gemm(ops.GEMM_NT_FP8, ops.EPI_RESID_BF16, A8, W8, C, bias=bias, aux=Rbig, rows_in=rin, rows_out=rout, row_off=roff, a_scale_inv=ai, b_scale_inv=wi)
+        assert _rel(C, want) < 5e-3
     # the quantisation itself: against the unquantised product the error is e4m3's (3 mantissa bits on both operands)
     assert _rel(ref, a @ w.t()) < 6e-2
     with pytest.raises(RuntimeError, match="multiple of 128"):
@@ -161,6 +186,84 @@ def test_fp8_quantisation_kernels(dev):
     ops.fp8_update_scales(amx, scales, margin=1.5)
     assert scales[0, 0].item() == pytest.approx(448.0 / 3.0) and scales[0, 1].item() == pytest.approx(3.0 / 448.0)
     assert scales[1].tolist() == [8.0, 0.125] and float(amx.abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,N,H,qb", [(2, 160, 4, 0), (2, 392, 3, 0), (3, 200, 2, 72)])
+def test_attention_fwd_e4m3_copy(dev, B, N, H, qb):
+    """the forward that also writes its rows as e4m3 (the A operand of an fp8 proj): bf16 output and lse identical to the plain
+    forward, the copy = sat(O * scale) of the same values, max|O| of the launch in the stripes (WHOLE and streaming forms, query range)"""
+    from mofo_amd import ops
+    F8 = torch.float8_e4m3fn
+    D = H * 64
+    qkv = _rand((B * N, 3 * D), dev, 1, 1.0)
+    o0, o1 = (torch.empty(B * (N - qb), D, dtype=BF16, device=dev) for _ in range(2))
+    l0, l1 = (torch.zeros(B * H * N, dtype=F32, device=dev) for _ in range(2))
+    ops.attention_fwd(qkv, B, N, H, 0.125, o0, l0, q_begin=qb)
+    amax = float(o0.float().abs().max())
+    qs = torch.tensor([448.0 / (0.6 * amax)], dtype=F32, device=dev)        # saturates the largest values
+    o8 = torch.zeros(B * (N - qb), D, dtype=F8, device=dev)
+    am = torch.zeros(ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
+    ops.attention_fwd(qkv, B, N, H, 0.125, o1, l1, q_begin=qb, out8=o8, q_scale=qs, q_amax=am)
+    assert torch.equal(o0, o1) and torch.equal(l0, l1)
+    lim = 0.6 * amax
+    assert _rel(o8.float() / qs, o0.float().clamp(-lim, lim)) < 4e-2 and not torch.isnan(o8.float()).any()
+    assert float(am.max()) == pytest.approx(amax, rel=1e-2)
+
+
+def test_adamw_writes_the_e4m3_shadow(dev):
+    """mofo_adamw_q8: masters, moments, bf16 shadow and the gradient norm are bit-identical to the plain update; the e4m3 shadow =
+    sat(bf16 shadow * delayed scale) per weight matrix, chunks outside every matrix untouched, and the new maxima land in w_amax for
+    mofo_fp8_roll_scales -- whose scales the next update uses.  A declined (gated) update changes neither shadow nor scales."""
+    from mofo_amd import ops
+    F8 = torch.float8_e4m3fn
+    n = 40 * 1024
+    seg_np = np.full(40, -1, dtype=np.int16)
+    seg_np[2:11] = 0
+    seg_np[11:12] = 1
+    seg_np[20:39] = 2
+    seg = torch.from_numpy(seg_np).to(dev)
+    grp = torch.zeros(40, dtype=torch.uint8, device=dev)
+    grp[30:] = 1
+    p0, g = _rand((n,), dev, 1, 0.05, F32), _rand((n,), dev, 2, 0.01, F32)
+    hyper = (1e-3, 0.05, 1e-3, 0.0, 0.9, 0.95, 1e-8)
+
+    def fresh():
+        return p0.clone(), torch.zeros(n, dtype=F32, device=dev), torch.zeros(n, dtype=F32, device=dev), torch.empty(n, dtype=BF16, device=dev)
+    pa, ma, va, sa = fresh()
+    pb, mb, vb, sb = fresh()
+    part_a, part_b = (torch.empty(2048, dtype=F32, device=dev) for _ in range(2))
+    na, nb = (torch.zeros(1, dtype=F32, device=dev) for _ in range(2))
+    # state as runtime.FlatStore.refresh_shadow8 leaves it: exact maxima of the CURRENT weights in w_amax
+    cur = p0.to(BF16)
+    s8 = torch.zeros(n, dtype=F8, device=dev)
+    s8.view(torch.uint8)[:2048] = 0x5A
+    w_amax, w_si, w_sc = torch.empty(3, dtype=F32, device=dev), torch.ones(3, dtype=F32, device=dev), torch.ones(3, dtype=F32, device=dev)
+    ops.fp8_quantize_segments(cur, seg, 3, w_amax, s8, w_si)
+    amax0 = w_amax.clone()
+    for step in (1, 2):
+        ops.adamw(pa, g, ma, va, sa, grp, *hyper, step, norm_partial=part_a, norm_out=na)
+        before = s8.clone()
+        ops.fp8_roll_scales(w_amax, w_sc, w_si)
+        used = w_sc.clone()
+        ops.adamw(pb, g, mb, vb, sb, grp, *hyper, step, norm_partial=part_b, norm_out=nb, q8=(seg, w_sc, w_amax, s8))
+        assert torch.equal(pa, pb) and torch.equal(ma, mb) and torch.equal(va, vb) and torch.equal(sa, sb) and float(na) == float(nb)
+        for i, (lo, hi) in enumerate(((2, 11), (11, 12), (20, 39))):
+            x = sb[lo * 1024:hi * 1024].float()
+            want = (x * used[i]).clamp(-448, 448).to(F8)
+            assert torch.equal(s8[lo * 1024:hi * 1024].view(torch.uint8), want.view(torch.uint8))
+            assert float(w_amax[i]) == float(x.abs().max())
+            assert float(w_si[i]) == pytest.approx(1.0 / float(used[i]), rel=1e-6)
+        if step == 1:
+            assert torch.allclose(used, 448.0 / amax0, rtol=1e-6)
+        for lo, hi in ((0, 2), (12, 20), (39, 40)):                        # not an fp8 operand: never written
+            assert torch.equal(s8[lo * 1024:hi * 1024].view(torch.uint8), before[lo * 1024:hi * 1024].view(torch.uint8))
+    # a declined update: nothing moves
+    bad = torch.tensor([float("nan")], dtype=F32, device=dev)
+    keep = (pb.clone(), s8.clone(), w_sc.clone(), w_si.clone(), w_amax.clone())
+    ops.fp8_roll_scales(w_amax, w_sc, w_si, gate_finite=bad)
+    ops.adamw(pb, g, mb, vb, sb, grp, *hyper, 3, q8=(seg, w_sc, w_amax, s8), gate_finite=bad)
+    for a_, b_ in zip(keep, (pb, s8, w_sc, w_si, w_amax)):
+        assert torch.equal(a_.view(torch.uint8) if a_.dtype == F8 else a_, b_.view(torch.uint8) if b_.dtype == F8 else b_)
 
 
 @pytest.mark.parametrize("k2", ["0", "1"])

@@ -1068,7 +1068,7 @@ def test_vit_large_32_frames_full_depth(dev, monkeypatch, fp8):
     assert float(loss.detach()) == pytest.approx(float(fx["loss"]), rel=1e-2 if fp8 else 1e-3)
     assert gn == pytest.approx(float(fx["grad_norm"]), rel=5e-2 if fp8 else 2e-2)
     w = model.runtime().ws(1, 320)
-    assert _rel(w.pred.view(1, 2816, 1536)[:, :6, :48], fx["out_slice"]) < (6e-2 if fp8 else 3e-2)
+    assert _rel(w.pred.view(1, 2816, 1536)[:, :6, :48], fx["out_slice"]) < (8e-2 if fp8 else 3e-2)    # (fp8: four e4m3 Linears in each of 28 blocks; 6.1e-2 measured)
     g = {n: p.grad for n, p in model.named_parameters()}
     names = [str(s) for s in fx["names"]]
     assert len(names) == len(g)
@@ -1184,8 +1184,8 @@ def test_vitl32_b32_step_parity(dev, monkeypatch):
 
 
 def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
-    """BASELINE configs[4] ("ViT-L 32x224x224 ... fp8 MFMA attention/MLP"): MOFO_FP8=1 runs the LayerNorm-fed forward Linears
-    (qkv, fc1) on OCP e4m3 operands with per-tensor scales.  Against the reference classes' fp32 fixture (vitl32.npz) and the
+    """BASELINE configs[4] ("ViT-L 32x224x224 ... fp8 MFMA attention/MLP"): MOFO_FP8=1 runs the four forward Linears of every block
+    (qkv, proj, fc1, fc2) on OCP e4m3 operands with per-tensor scales.  Against the reference classes' fp32 fixture (vitl32.npz) and the
     bf16 path.  Stated tolerances: e4m3 keeps 3 mantissa bits (2^-4 relative per element), the error of a K = 1024
     contraction averages down to ~1 % of an output's scale -- loss within 1e-2 of the reference (bf16: 1e-3), gradient norm
     within 5e-2, and within those bounds of the bf16 path; the weights' e4m3 shadow follows an optimizer step."""
@@ -1214,7 +1214,8 @@ def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
         out[tag] = (losses, norms)
         if tag == "fp8":
             st = rt.store
-            assert len(st.fp8_names) == 2 * (cfg.enc_depth + cfg.dec_depth)
+            assert len(st.fp8_names) == 4 * (cfg.enc_depth + cfg.dec_depth)     # qkv, proj, fc1, fc2 of every block
+            assert st.shadow8_current()                                         # written by the fused AdamW, not re-quantised
             n0 = "encoder.blocks.0.attn.qkv.weight"       # the e4m3 shadow is the quantised CURRENT bf16 shadow
             wq = st.b8view(n0).float() * st.w_si(n0)
             assert _rel(wq, st.bview(n0).float()) < 4e-2
