@@ -361,16 +361,25 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         if (qvalid) {
             store_T(out + ((size_t)b * nq + (qi - qb)) * ldo + h * HD, o0, o1, inv, hh);
             if (hh == 0) lse2[((size_t)b * H + h) * N + qi] = m * c + fast_log2(lt);
-            unsigned char* o8 = (unsigned char*)dqkv + ((size_t)b * nq + (qi - qb)) * lddqkv + h * HD;
+        }
+        // a lane holds 4 of every 8 consecutive d of its row (the other 4 on lane ^ 32): the two lanes trade one 4-byte word per 16 d,
+        // so each stores 8 contiguous bytes and a row's pair of lanes 16 -- half the store instructions of 4-byte pieces
+        unsigned char* o8 = (unsigned char*)dqkv + ((size_t)b * nq + ((qvalid ? qi : qb) - qb)) * lddqkv + h * HD;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) {
-                const f32x16& a = dt ? o1 : o0;
+        for (int dt = 0; dt < 2; ++dt) {
+            const f32x16& a = dt ? o1 : o0;
+            uint32_t wq[4];
 #pragma unroll
-                for (int rg = 0; rg < 4; ++rg) {
-                    const float v0 = a[4 * rg] * inv, v1 = a[4 * rg + 1] * inv, v2 = a[4 * rg + 2] * inv, v3 = a[4 * rg + 3] * inv;
-                    am = fmaxf(am, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
-                    *(uint32_t*)(o8 + 32 * dt + 8 * rg + 4 * hh) = pack4_e4m3(v0 * qs, v1 * qs, v2 * qs, v3 * qs);
-                }
+            for (int rg = 0; rg < 4; ++rg) {
+                const float v0 = a[4 * rg] * inv, v1 = a[4 * rg + 1] * inv, v2 = a[4 * rg + 2] * inv, v3 = a[4 * rg + 3] * inv;
+                if (qvalid) am = fmaxf(am, fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3))));
+                wq[rg] = pack4_e4m3(v0 * qs, v1 * qs, v2 * qs, v3 * qs);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const uint32_t got = (uint32_t)__shfl_xor((int)(hh ? wq[2 * j] : wq[2 * j + 1]), 32, 64);
+                const u32x2 o = hh ? u32x2{got, wq[2 * j + 1]} : u32x2{wq[2 * j], got};
+                if (qvalid) *(u32x2*)(o8 + 32 * dt + 16 * j + 8 * hh) = o;
             }
         }
         am = wave_max(am);      // every lane is still here (no early return above)

@@ -101,10 +101,14 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const void* __restrict__ xv
 
 // bf16 input with D <= 512 (the decoder's stream): one 16-B load per lane and row, TWO rows per wave in flight (the general
 // kernel's 8-B loads and one row per wave left ~24 KB in flight per CU: 3.3 TB/s on the 77 MB of a decoder LayerNorm).
+// Q8: also the e4m3 copy and the launch's max|y|, as ln_fwd_kernel<.., Q8> (8 bytes per lane and row).
+template <bool Q8 = false>
 __global__ __launch_bounds__(256) void ln_fwd_bf16_2row_kernel(const bf16_t* __restrict__ x, int ldx, const float* __restrict__ w,
                                                                 const float* __restrict__ b, float eps, int M, int D, int rows_in,
                                                                 int rows_out, int row_off, bf16_t* __restrict__ y, int ldy,
-                                                                float* __restrict__ mean, float* __restrict__ rstd) {
+                                                                float* __restrict__ mean, float* __restrict__ rstd,
+                                                                uint8_t* __restrict__ y8 = nullptr, int ldy8 = 0,
+                                                                const float* __restrict__ qscale = nullptr, float* __restrict__ amax_out = nullptr) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = (blockIdx.x * 4 + wave) * 2;
     if (r0 >= M) return;
@@ -155,6 +159,8 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_2row_kernel(const bf16_t* __r
         w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + c + 4);
         b0 = *(const f32x4*)(b + c), b1 = *(const f32x4*)(b + c + 4);
     }
+    float qs = 1.f, am = 0.f;
+    if constexpr (Q8) qs = qscale[0];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         if (k == 1 && r0 + 1 >= M) break;
@@ -169,8 +175,26 @@ __global__ __launch_bounds__(256) void ln_fwd_bf16_2row_kernel(const bf16_t* __r
                 o[e] = (v[k][e] - mu[k]) * rs[k] * w0[e] + b0[e];
                 o[4 + e] = (v[k][4 + e] - mu[k]) * rs[k] * w1[e] + b1[e];
             }
-            *(u32x4*)(y + (size_t)rr[k] * ldy + c) = u32x4{pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            const u32x4 pk = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+            *(u32x4*)(y + (size_t)rr[k] * ldy + c) = pk;
+            if constexpr (Q8) {     // what the bf16 consumers see (the rounded values), so both forms of the activation agree
+                float q[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    q[2 * e] = bf16lo_to_f32(pk[e]);
+                    q[2 * e + 1] = bf16hi_to_f32(pk[e]);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) am = fmaxf(am, fabsf(q[e]));
+                *(u32x2*)(y8 + (size_t)rr[k] * ldy8 + c) = u32x2{pack4_e4m3(q[0] * qs, q[1] * qs, q[2] * qs, q[3] * qs),
+                                                                 pack4_e4m3(q[4] * qs, q[5] * qs, q[6] * qs, q[7] * qs)};
+            }
         }
+    }
+    if constexpr (Q8) {
+        am = wave_max(am);
+        float* slot = amax_out + ((blockIdx.x * 4 + wave) & (MOFO_FP8_AMAX_STRIPES - 1));
+        if (lane == 0 && am > *(volatile const float*)slot) atomicMax((unsigned*)slot, __float_as_uint(am));
     }
 }
 
@@ -437,8 +461,8 @@ extern "C" int mofo_layernorm_fwd(const void* x, int x_is_bf16, int ldx, const f
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
     if (x_is_bf16 && D % 8 == 0 && D <= 512 && ldx % 8 == 0 && ldy % 8 == 0) {
-        hipLaunchKernelGGL(ln_fwd_bf16_2row_kernel, dim3(ceil_div(M, 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, eps, M, D, rows_in, rows_out,
-                           row_off, (bf16_t*)y, ldy, mean, rstd);
+        hipLaunchKernelGGL(ln_fwd_bf16_2row_kernel<false>, dim3(ceil_div(M, 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, eps, M, D, rows_in, rows_out,
+                           row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)nullptr, 0, (const float*)nullptr, (float*)nullptr);
         MOFO_CHECK_LAUNCH("mofo_layernorm_fwd");
         return MOFO_OK;
     }
@@ -460,6 +484,12 @@ extern "C" int mofo_layernorm_fwd_q(const void* x, int x_is_bf16, int ldx, const
     if (ldx % 4 || ldy % 4 || ldy8 % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_layernorm_fwd_q: leading dims must be multiples of 4");
     hipStream_t s = (hipStream_t)stream;
     const int nit = ceil_div(D, 256);
+    if (x_is_bf16 && D % 8 == 0 && D <= 512 && ldx % 8 == 0 && ldy % 8 == 0 && ldy8 % 8 == 0) {
+        hipLaunchKernelGGL(ln_fwd_bf16_2row_kernel<true>, dim3(ceil_div(M, 8)), dim3(256), 0, s, (const bf16_t*)x, ldx, w, b, eps, M, D, rows_in, rows_out,
+                           row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)y_e4m3, ldy8, qscale, amax_out);
+        MOFO_CHECK_LAUNCH("mofo_layernorm_fwd_q");
+        return MOFO_OK;
+    }
     dim3 grid(ceil_div(M, 4)), block(256);
 #define GO(N_) do { if (x_is_bf16) hipLaunchKernelGGL((ln_fwd_kernel<N_, true, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)y_e4m3, ldy8, qscale, amax_out); \
                     else hipLaunchKernelGGL((ln_fwd_kernel<N_, false, true>), grid, block, 0, s, x, ldx, w, b, eps, M, D, rows_in, rows_out, row_off, (bf16_t*)y, ldy, mean, rstd, (uint8_t*)y_e4m3, ldy8, qscale, amax_out); } while (0)
