@@ -1228,6 +1228,57 @@ def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
     assert lf[2] < lf[0]
 
 
+def test_fp8_shadow_follows_foreign_writes_and_range_updates(dev, monkeypatch):
+    """MOFO_FP8=1: (1) the fused AdamW keeps the e4m3 weight shadow current by itself (delayed per-matrix scale), whole-buffer and
+    range-by-range (the data-parallel update order); (2) after a write it did not make (load_state_dict) the next forward re-quantises
+    from the bf16 shadow with exact scales, and the fused path resumes with the update after it; (3) either way the e4m3 shadow
+    de-quantises to the current bf16 shadow within e4m3's resolution for EVERY fp8 matrix, and the loss tracks a bf16 twin."""
+    from mofo_amd import optim_factory
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(num_frames=4, img_size=64, enc_dim=256, enc_depth=2, enc_heads=4, dec_dim=128, dec_depth=2, dec_heads=2)
+    x = O.keyed_clips(2, cfg).to(dev)
+    np.random.seed(3)
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.75)] * 2)).bool().to(dev)
+
+    def consistent(st):
+        worst = 0.0
+        for n in st.fp8_names:
+            worst = max(worst, _rel(st.b8view(n).float() * st.w_si(n), st.bview(n).float()))
+        return worst
+
+    monkeypatch.setenv("MOFO_FP8", "1")
+    model, _ = _build(cfg, "xavier", dev)
+    rt, st = model.runtime(), model.runtime().store
+    assert rt.fp8 and len(st.fp8_names) == 4 * (cfg.enc_depth + cfg.dec_depth)
+    opt = optim_factory.create_optimizer(_Args, model)
+    sd0 = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    losses = []
+    for it in range(4):
+        loss = model.forward_loss(x, mask)
+        losses.append(float(loss.detach()))
+        opt.zero_grad()
+        loss.backward()
+        if it % 2 == 0:
+            opt.step()
+        else:       # the data-parallel order: range by range, each behind its own wait
+            lo_hi = [(0, 3 * 1024), (3 * 1024, st.total // 2 // 1024 * 1024), (st.total // 2 // 1024 * 1024, st.total)]
+            opt.step(ranges=[(lo, hi, lambda: None) for lo, hi in lo_hi])
+        assert st.shadow8_current() and consistent(st) < 4e-2
+    model.check_status()
+    assert losses[-1] < losses[0]
+    # a foreign write: the e4m3 shadow is stale until the next forward, whose exact re-quantisation the next update then continues
+    model.load_state_dict(sd0)
+    st.refresh_shadow()
+    assert not st.shadow8_current()
+    loss = model.forward_loss(x, mask)
+    assert st.shadow8_current() and consistent(st) < 4e-2
+    assert float(loss.detach()) == pytest.approx(losses[0], rel=2e-2)
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    assert st.shadow8_current() and consistent(st) < 4e-2
+
+
 # ----------------------------------------------------------------------------- "next" rows (SURVEY.md 8f-4)
 def _tiny(mode, dev):
     from oracle import pretrain_oracle as O
