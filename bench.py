@@ -372,6 +372,7 @@ def main():
                       "allreduce_value_check": None if ar_check is None else ("ok" if ar_check["ok"] else ("error: " + ar_check["error"] if "error" in ar_check else "fail")),
                       "allreduce_value_check_max_rel": None if ar_check is None or ar_check["max_rel"] != ar_check["max_rel"] else float("%.3e" % ar_check["max_rel"]),
                       "dp_route_ab": dp_ab, "grad_transport": ("bf16" if os.environ.get("MOFO_GRAD_BF16") == "1" else "f32") if (world > 1 or force_dp) else None,
+                      "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
                       "gpu_phase_s": round(gpu_phase_s, 2), "timed_s": round(dt, 3)}}
 
     if prof is not None:
