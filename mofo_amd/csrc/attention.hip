@@ -142,15 +142,16 @@ __device__ const float g_pad_row[2] = {1.0e30f, 0.f};   // (lse2, delta) of a qu
 // MODE 0: forward (writes out, lse2).  MODE 1: dQ pass of the backward (writes delta and the q part of dqkv).
 // WHOLE: the sequence is short (N <= 160: the encoder's visible tokens): all K/V tiles are staged once, one barrier,
 // and the tile loop runs without further loads or barriers (the streaming form spent its time in 5 load->barrier rounds).
-// Q8 (MODE 0 only; BASELINE configs[4]): the output rows also go out as OCP e4m3, sat(O * q_scale[0]) -- the A operand of an fp8 proj
-// GEMM -- and max|O| of the launch goes to the MOFO_FP8_AMAX_STRIPES stripes (delayed scaling, as the quantising LayerNorm).  The
-// forward leaves the backward's parameters unused and borrows three of them: dqkv / lddqkv = the e4m3 destination and its leading
-// dimension in bytes, dout = the device scalar q_scale, delta = the stripes.
+// Q8 (MODE 0 only; BASELINE configs[4]): the output rows also go out as OCP e4m3, out8 [.., ldo8 bytes] = sat(O * q_scale[0]) -- the A
+// operand of an fp8 proj GEMM -- and max|O| of the launch goes to the MOFO_FP8_AMAX_STRIPES stripes of q_amax (delayed scaling, as the
+// quantising LayerNorm).
 template <int NW, int MODE, bool WHOLE, bool U2 = false, bool Q8 = false>
 __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int nx, int G, int N, int H, float c,
                                                           float scale, bf16_t* __restrict__ out, int ldo,
                                                           float* __restrict__ lse2, const bf16_t* __restrict__ dout, int lddo,
-                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta, float thr, int qb) {
+                                                          bf16_t* __restrict__ dqkv, int lddqkv, float* __restrict__ delta, float thr, int qb,
+                                                          unsigned char* __restrict__ out8, int ldo8, const float* __restrict__ q_scale,
+                                                          float* __restrict__ q_amax) {
     // qb: first query row of every clip that is worked on (0 = all); `out` / `dout` then hold the N - qb rows of a clip COMPACTLY
     // ([B * (N - qb), H * 64]) while qkv, dqkv, lse2 and delta keep whole-sequence row indices.  The last decoder block's
     // visible-token queries feed nothing (modeling_pretrain.py:157 keeps x[:, -return_token_num:]): the runtime skips them.
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
     if constexpr (MODE == 0 && Q8) {
         const float lt = l + __shfl_xor(l, 32, 64);
         const float inv = 1.0f / lt;
-        const float qs = ((const float*)dout)[0];
+        const float qs = q_scale[0];
         float am = 0.f;
         if (qvalid) {
             store_T(out + ((size_t)b * nq + (qi - qb)) * ldo + h * HD, o0, o1, inv, hh);
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         }
         // a lane holds 4 of every 8 consecutive d of its row (the other 4 on lane ^ 32): the two lanes trade one 4-byte word per 16 d,
         // so each stores 8 contiguous bytes and a row's pair of lanes 16 -- half the store instructions of 4-byte pieces
-        unsigned char* o8 = (unsigned char*)dqkv + ((size_t)b * nq + ((qvalid ? qi : qb) - qb)) * lddqkv + h * HD;
+        unsigned char* o8 = out8 + ((size_t)b * nq + ((qvalid ? qi : qb) - qb)) * ldo8 + h * HD;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
             const f32x16& a = dt ? o1 : o0;
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
             }
         }
         am = wave_max(am);      // every lane is still here (no early return above)
-        float* slot = delta + ((blockIdx.x * NW + wave) & (MOFO_FP8_AMAX_STRIPES - 1));
+        float* slot = q_amax + ((blockIdx.x * NW + wave) & (MOFO_FP8_AMAX_STRIPES - 1));
         if (lane == 0 && am > *(volatile const float*)slot) atomicMax((unsigned*)slot, __float_as_uint(am));
         return;
     }
@@ -1108,12 +1109,13 @@ int pick_nw(int N) {
 }
 }  // namespace
 
-#define LAUNCH_Q(NW, MODE) do { if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false, false); } else { LAUNCH_Q_(NW, MODE, false, true, false); } } while (0)
+#define LAUNCH_Q(NW, MODE) do { void* out8 = nullptr; const int ldo8 = 0; const float* q_scale = nullptr; float* q_amax = nullptr; \
+                                if (N <= 160) { LAUNCH_Q_(NW, MODE, true, false, false); } else { LAUNCH_Q_(NW, MODE, false, true, false); } } while (0)
 #define LAUNCH_Q8(NW) do { if (N <= 160) { LAUNCH_Q_(NW, 0, true, false, true); } else { LAUNCH_Q_(NW, 0, false, true, true); } } while (0)
 #define LAUNCH_Q_(NW, MODE, WH, U2, Q8)                                                                                 \
     hipLaunchKernelGGL((attn_q_kernel<NW, MODE, WH, U2, Q8>), dim3(8 * ceil_div(B * H, 8) * ceil_div(N - q_begin, 32 * NW)), dim3(NW * 64), 0, s, \
                        (const bf16_t*)qkv, ldqkv, ceil_div(N - q_begin, 32 * NW), B * H, N, H, c, scale, (bf16_t*)out, ldo, (float*)lse2, \
-                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr(), q_begin)
+                       (const bf16_t*)dout, lddo, (bf16_t*)dqkv, lddqkv, delta, rescale_thr(), q_begin, (unsigned char*)out8, ldo8, q_scale, q_amax)
 
 static int check_common(const char* who, const void* qkv, int ldqkv, int B, int N, int H) {
     if (!qkv) MOFO_FAIL(MOFO_EINVAL, "%s: null qkv", who);
@@ -1161,8 +1163,8 @@ extern "C" int mofo_attention_fwd_q8(const void* qkv, int ldqkv, int B, int N, i
     if (ldo < H * 64 || ldo % 4 || ldo8 < H * 64 || ldo8 % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd_q8: bad ldo=%d / ldo8=%d", ldo, ldo8);
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
-    // the forward kernel's unused backward parameters carry the e4m3 destination, its scale and the amax stripes (attn_q_kernel: Q8)
-    const void* dout = q_scale; int lddo = 0; void* dqkv = out_e4m3; int lddqkv = ldo8; float* delta = q_amax;
+    const void* dout = nullptr; int lddo = 0; void* dqkv = nullptr; int lddqkv = 0; float* delta = nullptr;
+    void* out8 = out_e4m3;
     switch (pick_nw(N)) {
         case 5: LAUNCH_Q8(5); break;
         default: LAUNCH_Q8(4); break;

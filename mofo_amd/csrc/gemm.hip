@@ -930,12 +930,12 @@ __global__ __launch_bounds__(512, 2) void gemm_ksplit_kernel(GemmP p, int total)
                         (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false);
 }
 
-// NT on OCP e4m3 operands (BASELINE configs[4]: "fp8 MFMA attention/MLP"; here the forward Linears whose A operand is a
-// LayerNorm output: qkv and fc1).  One byte per element, so a 128-row x 128-BYTE operand tile has exactly the bf16 ROW
-// image's geometry (128-B rows, 16-B chunk c of row r at c ^ (r & 7)) with twice the reduction depth; the MFMA is the
-// block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit (e8m0 = 127) block scales -- 2x the bf16 rate -- and lane l feeds
-// row l & 15, reduction bytes 32 (l >> 4) .. + 31 (two ds_read_b128).  Two LDS stages, LDS-DMA staging, the shared epilogue
-// with the per-tensor de-quantisation factor a_scale_inv * b_scale_inv applied to the f32 accumulators.
+// NT on OCP e4m3 operands (BASELINE configs[4]: "fp8 MFMA attention/MLP"; here the four forward Linears of a block).  One byte
+// per element, so a 128-row x 128-BYTE operand tile has exactly the bf16 ROW image's geometry (128-B rows, 16-B chunk c of row r
+// at c ^ (r & 7)) with twice the reduction depth; the MFMA is the block-scaled v_mfma_scale_f32_16x16x128_f8f6f4 with unit
+// (e8m0 = 127) block scales -- 2x the bf16 rate -- and lane l feeds row l & 15, reduction bytes 32 (l >> 4) .. + 31 (two
+// ds_read_b128).  LDS-DMA staging, the shared epilogue with the per-tensor de-quantisation factor a_scale_inv * b_scale_inv applied to
+// the f32 accumulators.  (Rounds 2-4 ran a two-stage one-tile-per-block kernel here: 3-24 % slower, profiles/r05_gemm_fp8_ab.txt.)
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 template <int NI>
 __device__ __forceinline__ void stage_tile_bytes(__amdgpu_buffer_rsrc_t rsrc, int voff, int ld, int d0, int k0, unsigned char* lds_tile, int wave_u) {
@@ -955,68 +955,7 @@ __device__ __forceinline__ i32x8 read_frag_fp8(const unsigned char* lds_tile, in
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3]; r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
 }
-template <int EPI, int MI>
-__global__ __launch_bounds__(256, 2) void gemm_fp8_kernel(GemmP p, int total) {
-    constexpr int BMT = 32 * MI;
-    constexpr int A_BYTES = BMT * 128;
-    constexpr int STG = A_BYTES + 128 * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STG];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + BN - 1) / BN;
-    int m0, n0;
-    {
-        const int w = blockIdx.x;
-        const int q = total >> 3, r = total & 7, xcd = w & 7;
-        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (w >> 3);
-        m0 = (wg / tiles_n) * BMT;
-        n0 = (wg % tiles_n) * BN;
-    }
-    const int nk = p.K / 128;
-    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, (int)(((size_t)p.M - 1) * p.lda + p.K), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc((void*)p.B, 0, (int)(((size_t)p.N - 1) * p.ldb + p.K), 0x00020000);
-    const int va = (lane >> 3) * p.lda + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-    const int vb = (lane >> 3) * p.ldb + (((lane & 7) ^ ((lane >> 3) & 7)) << 4);
-    auto stage = [&](int t, int buf) {
-        unsigned char* ta = smem + buf * STG;
-        stage_tile_bytes<MI>(ra, va, p.lda, m0, t * 128, ta, wave_u);
-        stage_tile_bytes<4>(rb, vb, p.ldb, n0, t * 128, ta + A_BYTES, wave_u);
-    };
-    f32x4 acc[MI][4];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float alpha = p.a_scale_inv[0] * p.b_scale_inv[0];
-    stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    int cur = 0;
-    for (int t = 0; t < nk; ++t) {
-        if (t + 1 < nk) stage(t + 1, cur ^ 1);
-        const unsigned char* ta = smem + cur * STG;
-        const unsigned char* tb = ta + A_BYTES;
-        i32x8 af[MI], bfr[4];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[i] = read_frag_fp8(ta, wm * (16 * MI) + 16 * i, lane);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) bfr[i] = read_frag_fp8(tb, wn * 64 + 16 * i, lane);
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)   // (B, A) operand order as in the bf16 kernels: a lane ends up with 4 consecutive n of one m
-                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(bfr[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        cur ^= 1;
-    }
-    static_assert(4 * (16 * MI) * 64 * 4 <= 2 * STG, "epilogue staging must fit the main-loop LDS");
-    epilogue<EPI, MI, 1, true>(p, acc, (float*)smem + wave * ((16 * MI) * 64), m0 + wm * (16 * MI), n0 + wn * 64,
-                               (m0 + BMT <= p.M) && (n0 + BN <= p.N), lane, false, alpha);
-}
-
-// PERSISTENT e4m3 form (round 5): the bf16 persistent kernel's schedule on one-byte operands.  A 128-B LDS row holds 128 reduction
+// The bf16 persistent kernel's schedule on one-byte operands.  A 128-B LDS row holds 128 reduction
 // elements instead of 64 and one v_mfma_scale_f32_16x16x128_f8f6f4 (8 passes) does the work of four bf16 16x16x32 MFMAs (4 passes
 // each): a k-stage costs the same LDS bytes, fragment registers (8 VGPRs per 16-row sub-tile) and matrix-pipe cycles as a bf16
 // k-stage and covers TWICE the reduction.  One LDS stage + register double buffering (3 blocks / CU at MI <= 4), the next tile's
@@ -1245,6 +1184,7 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
             MOFO_FAIL(MOFO_EINVAL, "mofo_gemm NT_FP8: the e4m3 activation copy (C8) rides on BIAS_GELU and needs q_scale, q_amax, ldc8 a multiple of 8");
         if ((a->splits > 1) || a->accumulate) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NT_FP8: no split-K / accumulate");
     }
+    if (a->C8 && op != MOFO_GEMM_NT_FP8) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: the e4m3 activation copy (C8) exists for op NT_FP8 + BIAS_GELU only");
     if (op == MOFO_GEMM_NN && a->K % 64) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm NN: K=%d must be a multiple of 64", a->K);
     if (op == MOFO_GEMM_TN && a->M % 8) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm TN: M=%d must be a multiple of 8", a->M);
     const bool out_bf16 = (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU || epi == MOFO_EPI_DGELU_BF16 || epi == MOFO_EPI_RESID_BF16 ||
@@ -1339,16 +1279,7 @@ static int dispatch(int op, int epi, const GroupP& g, int mi, hipStream_t s) {
         if (mi == 2) hipLaunchKernelGGL((gemm_fp8_persistent_kernel<E, 2>), pgrid, block, 0, s, p, total);               \
         else hipLaunchKernelGGL((gemm_fp8_persistent_kernel<E, 4>), pgrid, block, 0, s, p, total);                       \
     } while (0)
-        const char* ef = getenv("MOFO_FP8_FORM");     // 0: the one-tile-per-block two-stage kernel of rounds 2-4 (A/B tools)
-        if (ef && atoi(ef) == 0 && (epi == MOFO_EPI_BF16 || epi == MOFO_EPI_BIAS_GELU)) {
-            if (epi == MOFO_EPI_BF16) {
-                if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 2>), dim3(total), dim3(256), 0, s, p, total);
-                else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BF16, 4>), dim3(total), dim3(256), 0, s, p, total);
-            } else {
-                if (mi == 2) hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 2>), dim3(total), dim3(256), 0, s, p, total);
-                else hipLaunchKernelGGL((gemm_fp8_kernel<MOFO_EPI_BIAS_GELU, 4>), dim3(total), dim3(256), 0, s, p, total);
-            }
-        } else if (epi == MOFO_EPI_BF16) GO8(MOFO_EPI_BF16);
+        if (epi == MOFO_EPI_BF16) GO8(MOFO_EPI_BF16);
         else if (epi == MOFO_EPI_BIAS_GELU) GO8(MOFO_EPI_BIAS_GELU);
         else if (epi == MOFO_EPI_RESID_F32) GO8(MOFO_EPI_RESID_F32);
         else if (epi == MOFO_EPI_RESID_BF16) GO8(MOFO_EPI_RESID_BF16);

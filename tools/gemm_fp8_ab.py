@@ -4,8 +4,8 @@ the default bf16 route, per GEMM, in ONE process on one device (GPU box only).  
 row of BASELINE configs[4] is called closed.
 
 For every shape: the bf16 NT GEMM through the default routing, the e4m3 GEMM (operands quantised per tensor beforehand: in the
-model the LayerNorm / attention / GELU epilogues and AdamW write them), and -- MOFO_FP8_FORM=0 -- the one-tile-per-block e4m3 kernel
-of rounds 2-4 where it is built.  Results are checked against an fp32 torch product of the SAME (de-quantised) operands.
+model the LayerNorm / attention / GELU epilogues and AdamW write them).  (The "old e4m3" column of profiles/r05_gemm_fp8_ab.txt was the
+one-tile-per-block kernel of rounds 2-4, deleted after that record.)  Results are checked against an fp32 torch product of the SAME (de-quantised) operands.
 Interleaved timing rounds, 20 ms of the same variant first (steady state), median and min.
 usage: gemm_fp8_ab.py [vitl|vitb|all] [rounds]      (MOFO_GEMM_MI8=1 in the environment forces 256-row tiles for both arms)"""
 import os
@@ -37,7 +37,6 @@ def make(epi, M, N, K):
     ref16 = lambda: A.float() @ B.float().t() + bias
     ref8 = lambda: (A8.float() * a_si) @ (B8.float() * b_si).t() + bias
     kw16, kw8, post = {}, {}, lambda z: z
-    extra = []
     if epi == E.EPI_BF16:
         C16, C8o = (torch.empty(M, N, dtype=BF16, device=dev) for _ in range(2))
     elif epi == E.EPI_BIAS_GELU:
@@ -48,8 +47,6 @@ def make(epi, M, N, K):
         qam = torch.zeros(ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
         kw16 = dict(C2=G16)
         kw8 = dict(C2=G8o, C8=Gq, q_scale=qs, q_amax=qam)
-        extra = [("gelu", G8o, lambda: torch.nn.functional.gelu(ref8())),
-                 ("gelu e4m3", None, lambda: None)]
     elif epi == E.EPI_RESID_F32:
         C16, C8o = (torch.empty(M, N, dtype=F32, device=dev) for _ in range(2))
         R = torch.randn(M, N, device=dev)
@@ -119,7 +116,7 @@ def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "vitl"
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 5
     names = list(SETS) if which == "all" else which.split(",")
-    print(f"{'shape':<18}{'M':>7}{'N':>6}{'K':>6} | err bf16   e4m3(same ops)  e4m3 vs bf16 ops | bf16 us (min)    e4m3 us (min)    old e4m3 us | TF/s bf16  e4m3  ratio")
+    print(f"{'shape':<18}{'M':>7}{'N':>6}{'K':>6} | err bf16   e4m3(same ops)  e4m3 vs bf16 ops | bf16 us (min)    e4m3 us (min)    | TF/s bf16  e4m3  ratio")
     for nm in names:
         for label, epi, M, N, K in SETS[nm]:
             torch.manual_seed(0)
@@ -129,18 +126,12 @@ def main():
             flops = 2.0 * M * N * K
             iters = max(3, min(200, int(4e-3 / (flops / 600e12))))
             warm = max(3, int(20e-3 / (flops / 600e12)))
-            t16, t8, told = [], [], []
-            old_ok = epi in (E.EPI_BF16, E.EPI_BIAS_GELU)
+            t16, t8 = [], []
             for _ in range(rounds):
                 t16.append(timed(run16, iters, warm))
                 t8.append(timed(run8, iters, warm))
-                if old_ok:
-                    os.environ["MOFO_FP8_FORM"] = "0"
-                    told.append(timed(run8, iters, warm))
-                    del os.environ["MOFO_FP8_FORM"]
             m16, m8 = statistics.median(t16), statistics.median(t8)
-            olds = f"{statistics.median(told):9.1f}" if told else "        -"
-            print(f"{label:<18}{M:>7}{N:>6}{K:>6} | {e16:.2e}  {e8:.2e}  {e8q:.2e} {ok:>4} | {m16:8.1f} ({min(t16):7.1f}) {m8:8.1f} ({min(t8):7.1f}) {olds} |"
+            print(f"{label:<18}{M:>7}{N:>6}{K:>6} | {e16:.2e}  {e8:.2e}  {e8q:.2e} {ok:>4} | {m16:8.1f} ({min(t16):7.1f}) {m8:8.1f} ({min(t8):7.1f}) |"
                   f" {flops / m16 / 1e6:7.0f} {flops / m8 / 1e6:7.0f}  {m16 / m8:5.2f}x{msg}", flush=True)
 
 
