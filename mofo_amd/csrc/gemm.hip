@@ -164,8 +164,8 @@ __device__ __forceinline__ void stage_tile_srd(__amdgpu_buffer_rsrc_t rsrc, int 
     for (int j = 0; j < NI; ++j) {
         const int i = wave_u * NI + j;
         if constexpr (LAYOUT == OPL_ROW) {
-            // unsigned: a tile row offset past the operand (ragged last tile) may exceed INT_MAX bytes for operands close to
-            // the 2 GiB extent limit that fill_problem enforces; the SRD range check then reads zeros
+            // unsigned: operands reach up to 4 GiB (fill_problem keeps a tile of slack below it, so a row offset past the
+            // operand -- ragged last tile -- does not wrap); the SRD range check then reads zeros
             const unsigned soff = ((unsigned)(d0 + 8 * i) * (unsigned)ld + (unsigned)k0) * 2u;
             if constexpr (ASM) lds_dma16<false>(rsrc, lds_tile + i * 1024, v0, soff);
             else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, LDS_PTR(lds_tile + i * 1024), 16, v0, (int)soff, 0, AUX);
@@ -1201,17 +1201,20 @@ static int fill_problem(const mofo_gemm_args* a, GemmP& p, int bm, int bn, int& 
         (a->rows_in < 0 || a->rows_out < a->rows_in || a->row_off < 0 || a->row_off + a->rows_in > a->rows_out || a->M % a->rows_in))
         MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: residual row map needs 0 < rows_in <= rows_out - row_off and M a multiple of rows_in");
     {
-        // the operands are addressed through 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets):
-        // an operand image of 2 GiB or more is refused instead of wrapping (split the rows / the reduction on the caller's side)
+        // the operands are addressed through UNSIGNED 32-bit buffer offsets (SRD extent, per-lane and per-tile byte offsets; every
+        // offset is formed in unsigned arithmetic and the descriptor's num_records is unsigned): an operand image of 4 GiB or more is
+        // refused instead of wrapping (split the rows / the reduction on the caller's side).  ViT-L, 32 frames, 256 clips per GPU: the
+        // decoder's fc1 output is 3.3 GB, its qkv 2.5 GB.
         const long long ra = op == MOFO_GEMM_TN ? a->K : a->M, ca = op == MOFO_GEMM_TN ? a->M : a->K;
         const bool ntlike = op == MOFO_GEMM_NT || op == MOFO_GEMM_NT_FP8;
         const long long rb = ntlike ? a->N : a->K, cb = ntlike ? a->K : a->N;
         const long long esz = op == MOFO_GEMM_NT_FP8 ? 1 : 2;
         const long long ext_a = ((ra - 1) * a->lda + ca) * esz, ext_b = ((rb - 1) * a->ldb + cb) * esz;
-        // + one ragged tile of slack: offsets of rows past the end are formed before the range check drops them
-        const long long slack = 256LL * (a->lda > a->ldb ? a->lda : a->ldb) * 2;
-        if (ext_a + slack >= (1LL << 31) || ext_b + slack >= (1LL << 31))
-            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: operand extent %lld / %lld bytes is beyond the 2 GiB the 32-bit buffer offsets address",
+        // + slack: offsets of rows past the end (a ragged last tile; the k-stages the ring kernels issue past the end of the reduction)
+        // are formed before the range check drops them, and must not wrap into the operand
+        const long long slack = 1024LL * (a->lda > a->ldb ? a->lda : a->ldb) * 2;
+        if (ext_a + slack >= (1LL << 32) || ext_b + slack >= (1LL << 32))
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm: operand extent %lld / %lld bytes is beyond the 4 GiB the 32-bit buffer offsets address",
                       ext_a, ext_b);
         if (a->lda < ca || a->ldb < cb) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm: leading dimension smaller than the row length");
     }

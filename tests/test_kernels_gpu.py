@@ -672,20 +672,62 @@ def test_gemm_rejects_bad_shapes(dev):
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.float(), B, C)
     with pytest.raises(ValueError):
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A.cpu(), B, C)
-    # operands are addressed with 32-bit buffer offsets: an operand image of 2 GiB or more is refused, not wrapped
-    big = torch.empty((1 << 20) + 128, 1024, dtype=BF16, device=dev)          # 2 GiB + 256 KiB
+    # operands are addressed with UNSIGNED 32-bit buffer offsets: an operand image of 4 GiB or more is refused, not wrapped
+    big = torch.empty((1 << 21) + 128, 1024, dtype=BF16, device=dev)          # 4 GiB + 256 KiB
     Wt = _rand((128, 1024), dev, 3)
     out = torch.empty(big.shape[0], 128, dtype=BF16, device=dev)
-    with pytest.raises(RuntimeError, match="2 GiB"):
+    with pytest.raises(RuntimeError, match="4 GiB"):
         ops.gemm(ops.GEMM_NT, ops.EPI_BF16, big, Wt, out)
-    with pytest.raises(RuntimeError, match="2 GiB"):                          # ... as the reduction-strided operand of a wgrad
+    with pytest.raises(RuntimeError, match="4 GiB"):                          # ... as the reduction-strided operand of a wgrad
         ops.gemm(ops.GEMM_TN, ops.EPI_F32, big, big[:, :128], torch.empty(1024, 128, dtype=torch.float32, device=dev))
-    # just below the limit still runs (1.75 GiB operand, ragged last tile) and agrees with torch on the last rows
-    ok = big[: 917504 - 40]
-    ok[-256:] = _rand((256, 1024), dev, 4)
-    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, ok, Wt, out[: ok.shape[0]])
-    ref = ok[-256:].float() @ Wt.float().t()
-    assert float((out[ok.shape[0] - 256: ok.shape[0]].float() - ref).norm() / ref.norm()) < 1e-2
+
+
+def test_gemm_operands_between_2_and_4_gib(dev):
+    """Operand images beyond 2 GiB (the decoder's qkv / fc1 activations of ViT-L, 32 frames, at 256 clips per GPU: 2.5 / 3.3 GB): every
+    buffer offset is unsigned, so up to 4 GiB minus a tile of slack is addressed.  NT (bf16 and e4m3) with a ragged last tile: rows
+    below 2 GiB, across it and at the very end against torch; TN (the weight gradient: the big operand is reduction-strided, split-K
+    with atomics and the unsplit ring route) against a chunked fp32 torch reduction."""
+    from mofo_amd import ops
+    F8 = torch.float8_e4m3fn
+    g = torch.Generator(device=dev).manual_seed(11)
+    M = 1_800_000 - 40                                                         # 3.69 GB of bf16 at K = 1024
+    big = torch.empty(M, 1024, dtype=BF16, device=dev)
+    for lo in range(0, M, 200_000):                                            # filled in pieces: no 7-GB f32 temporary
+        hi = min(M, lo + 200_000)
+        big[lo:hi] = torch.randn(hi - lo, 1024, generator=g, device=dev).to(BF16)
+    Wt = _rand((128, 1024), dev, 3, 0.05)
+    out = torch.empty(M, 128, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT, ops.EPI_BF16, big, Wt, out)
+    two_gib_row = (1 << 31) // 2048
+    for lo in (0, two_gib_row - 300, M - 700):
+        ref = big[lo:lo + 700].float() @ Wt.float().t()
+        assert _rel(out[lo:lo + 700], ref) < 6e-3, lo
+    # e4m3: 3.0 GB of one-byte rows
+    M8 = 2_900_000 + 24
+    a8 = torch.empty(M8, 1024, dtype=F8, device=dev)
+    for lo in range(0, M8, 400_000):
+        hi = min(M8, lo + 400_000)
+        a8[lo:hi] = (torch.randn(hi - lo, 1024, generator=g, device=dev) * 100.0).clamp(-448, 448).to(F8)
+    w8 = (torch.randn(128, 1024, generator=g, device=dev) * 100.0).clamp(-448, 448).to(F8)
+    one = torch.tensor([1e-2], dtype=F32, device=dev)
+    out8 = torch.empty(M8, 128, dtype=BF16, device=dev)
+    ops.gemm(ops.GEMM_NT_FP8, ops.EPI_BF16, a8, w8, out8, a_scale_inv=one, b_scale_inv=one)
+    for lo in (0, (1 << 31) // 1024 - 300, M8 - 700):
+        ref = (a8[lo:lo + 700].float() @ w8.float().t()) * 1e-4
+        assert _rel(out8[lo:lo + 700], ref) < 6e-3, lo
+    del a8, out8
+    # TN: dW[m, n] = sum_k big[k, m] * big[k, n0 + n] over 1.8 M rows (every row beyond 2 GiB takes part in every output)
+    Bv = big[:, 256:384]
+    ref = torch.zeros(1024, 128, dtype=torch.float64, device=dev)
+    for lo in range(0, M, 100_000):
+        hi = min(M, lo + 100_000)
+        ref += (big[lo:hi].float().t() @ Bv[lo:hi].float()).double()
+    Cw = torch.zeros(1024, 128, dtype=F32, device=dev)
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, big, Bv, Cw, splits=64)
+    assert _rel(Cw, ref.float()) < 1e-4
+    Cw.fill_(float("nan"))
+    ops.gemm(ops.GEMM_TN, ops.EPI_F32, big, Bv, Cw)                            # unsplit, overwrite
+    assert _rel(Cw, ref.float()) < 1e-4
 
 
 def test_colsum(dev):

@@ -1183,6 +1183,51 @@ def test_vitl32_b32_step_parity(dev, monkeypatch):
     assert worst[1] < 2e-2, worst
 
 
+@pytest.mark.parametrize("fp8", [False, True])
+def test_vitl32_b256_operands_beyond_2_gib(dev, monkeypatch, fp8):
+    """BASELINE configs[4] "batch sized to 288 GB HBM": ViT-L, 32 frames, 256 clips on one GPU (about 200 GB allocated).  The decoder's qkv
+    (2.5 GB), fc1 pre-activation / activation (3.3 GB each) and their gradients lie beyond 2 GiB, where a signed byte offset would wrap:
+    every GEMM family the routing picks there (forward, dgrad, grouped weight gradients), the attention and LayerNorm kernels must
+    address them.  The batch is EIGHT COPIES of the 32 clips and masks of the B = 32 test, so the mean loss and the mean gradient must
+    equal those of the 32-clip batch (itself pinned to one-clip runs and the reference by test_vitl32_b32_step_parity)."""
+    from oracle import pretrain_oracle as O
+    if torch.cuda.mem_get_info()[1] < 260e9:
+        pytest.skip("needs a 288 GB device")
+    monkeypatch.setenv("MOFO_FP8", "1" if fp8 else "0")
+    monkeypatch.delenv("MOFO_GEMM8", raising=False)
+    cfg = O.OracleConfig(num_frames=32, enc_dim=1024, enc_depth=24, enc_heads=16, dec_dim=512, dec_depth=4, dec_heads=8)
+    model, _ = _build(cfg, "xavier", dev)
+    store = model.runtime().store
+    x = O.keyed_clips(32, cfg).to(dev)
+    np.random.seed(7)
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.9) for _ in range(32)])).bool().to(dev)
+    out = {}
+    for rep in (1, 8):
+        xs, ms = (x, mask) if rep == 1 else (x.repeat(rep, 1, 1, 1, 1), mask.repeat(rep, 1))
+        for _ in range(2 if fp8 else 1):      # delayed scaling: the second forward of a batch size runs on scales this data left
+            loss = model.forward_loss(xs, ms)
+        store.zero_grads()
+        loss.backward()
+        model.check_status()
+        out[rep] = (float(loss.detach()), store.grads.clone())
+        del xs, ms
+    (l1, g1), (l8, g8) = out[1], out[8]
+    tol_l, tol_g = (2e-3, 3e-2) if fp8 else (2e-4, 1e-2)      # (fp8: the two batch sizes' activation maxima are equal, the scales' history is not)
+    assert l8 == pytest.approx(l1, rel=tol_l)
+    total = float(g1.double().norm())
+    assert float(g8.double().norm()) == pytest.approx(total, rel=tol_l * 10)
+    worst = ("", 0.0)
+    for n in store.names:
+        o = store.offset[n]
+        k = int(np.prod(store.shape[n]))
+        if float(g1[o:o + k].double().norm()) < 2e-4 * total:
+            continue
+        r = _rel(g8[o:o + k], g1[o:o + k])
+        if r > worst[1]:
+            worst = (n, r)
+    assert worst[1] < tol_g, worst
+
+
 def test_vit_large_32_frames_fp8_forward(dev, monkeypatch):
     """BASELINE configs[4] ("ViT-L 32x224x224 ... fp8 MFMA attention/MLP"): MOFO_FP8=1 runs the four forward Linears of every block
     (qkv, proj, fc1, fc2) on OCP e4m3 operands with per-tensor scales.  Against the reference classes' fp32 fixture (vitl32.npz) and the
