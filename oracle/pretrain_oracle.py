@@ -222,13 +222,23 @@ def ingest_uint8(frames: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- forward pieces
+# LIBRARY_OPS (bench.py's eager baseline only): the same forward through the torch library ops the reference's nn.Modules call
+# (F.linear / F.layer_norm / F.gelu / softmax) instead of the elementary ops below -- what "the reference under PyTorch" costs on a
+# device, not a different arithmetic (tests/test_oracle_golden.py holds the two forms together on CPU).  Works on any device.
+LIBRARY_OPS = False
+
+
 def _linear(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if LIBRARY_OPS:
+        return torch.nn.functional.linear(x, w, b)
     y = x @ w.t()
     return y if b is None else y + b
 
 
 def _layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) -> torch.Tensor:
     """nn.LayerNorm: biased variance over the last dim, eps inside the sqrt."""
+    if LIBRARY_OPS:
+        return torch.nn.functional.layer_norm(x, (x.shape[-1],), w, b, eps)
     mu = x.mean(dim=-1, keepdim=True)
     xc = x - mu
     var = (xc * xc).mean(dim=-1, keepdim=True)
@@ -237,6 +247,8 @@ def _layernorm(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, eps: float) ->
 
 def _gelu_erf(x: torch.Tensor) -> torch.Tensor:
     """nn.GELU() default = exact erf form (modeling_finetune.py:35,40)."""
+    if LIBRARY_OPS:
+        return torch.nn.functional.gelu(x)
     return 0.5 * x * (1.0 + torch.erf(x * (1.0 / math.sqrt(2.0))))
 
 
@@ -266,9 +278,12 @@ def attention(x: torch.Tensor, P: Dict[str, torch.Tensor], pre: str, heads: int)
     qkv = _linear(x, P[pre + "attn.qkv.weight"], bias).reshape(B, N, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q, k, v = qkv[0] * (hd ** -0.5), qkv[1], qkv[2]
     s = q @ k.transpose(-2, -1)
-    s = s - s.max(dim=-1, keepdim=True).values
-    e = torch.exp(s)
-    p = e / e.sum(dim=-1, keepdim=True)
+    if LIBRARY_OPS:
+        p = s.softmax(dim=-1)
+    else:
+        s = s - s.max(dim=-1, keepdim=True).values
+        e = torch.exp(s)
+        p = e / e.sum(dim=-1, keepdim=True)
     o = (p @ v).transpose(1, 2).reshape(B, N, D)
     return _linear(o, P[pre + "attn.proj.weight"], P[pre + "attn.proj.bias"])
 
@@ -285,7 +300,7 @@ def block(x: torch.Tensor, P: Dict[str, torch.Tensor], pre: str, heads: int, eps
 def encoder_forward(x: torch.Tensor, mask: torch.Tensor, P: Dict[str, torch.Tensor], cfg: OracleConfig,
                     taps: Optional[dict] = None) -> torch.Tensor:
     """modeling_pretrain.py:83-101."""
-    tok = patch_embed(x, P, cfg) + sincos_table(cfg.num_patches, cfg.enc_dim)
+    tok = patch_embed(x, P, cfg) + sincos_table(cfg.num_patches, cfg.enc_dim).to(x.device)
     B, _, C = tok.shape
     xv = tok[~mask].reshape(B, -1, C)
     if taps is not None:
@@ -319,7 +334,7 @@ def model_forward(x: torch.Tensor, mask: torch.Tensor, P: Dict[str, torch.Tensor
         taps["enc_out"] = xv
     xv = _linear(xv, P["encoder_to_decoder.weight"])
     B, _, C = xv.shape
-    pos = sincos_table(cfg.num_patches, cfg.dec_dim).expand(B, -1, -1)
+    pos = sincos_table(cfg.num_patches, cfg.dec_dim).to(xv.device).expand(B, -1, -1)
     pos_vis = pos[~mask].reshape(B, -1, C)
     pos_msk = pos[mask].reshape(B, -1, C)
     full = torch.cat([xv + pos_vis, P["mask_token"] + pos_msk], dim=1)
@@ -332,8 +347,8 @@ def build_targets(x: torch.Tensor, mask: torch.Tensor, cfg: OracleConfig, normal
     """engine_for_pretraining.py:43-63: un-normalise with the ImageNet constants, cut into tubelets with
     feature order (p0 p1 p2) c, per (token, channel) standardise over the 512 pixels with the UNBIASED
     variance and 1e-6 added AFTER the sqrt, flatten to (p c) and keep the masked tokens."""
-    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype)[None, :, None, None, None]
-    std = torch.tensor(IMAGENET_STD, dtype=x.dtype)[None, :, None, None, None]
+    mean = torch.tensor(IMAGENET_MEAN, dtype=x.dtype, device=x.device)[None, :, None, None, None]
+    std = torch.tensor(IMAGENET_STD, dtype=x.dtype, device=x.device)[None, :, None, None, None]
     u = x * std + mean
     B, C, T, H, W = u.shape
     pt, p = cfg.tubelet, cfg.patch_size

@@ -133,6 +133,22 @@ def test_tiny_full_parity(mode):
     assert sorted(g["group_sizes"].tolist()) == sorted([decay, len(P) - decay])
 
 
+def test_library_ops_form_is_the_same_arithmetic(monkeypatch):
+    """O.LIBRARY_OPS (bench.py's eager baseline) routes the forward through F.linear / F.layer_norm / F.gelu / softmax: the fixture's output
+    and first-step loss / gradient norm to the tolerances the elementary form is held to"""
+    g = _load("tiny_small.npz")
+    cfg = O.TINY
+    P = O.keyed_params(cfg, "small")
+    x = O.keyed_clips(2, cfg)
+    mask = torch.from_numpy(_load("masks.npz")["tube_tiny_s10"]).bool()
+    monkeypatch.setattr(O, "LIBRARY_OPS", True)
+    with torch.no_grad():
+        out = O.model_forward(x, mask, P, cfg)
+    np.testing.assert_allclose(out.numpy(), g["output"], rtol=1e-4, atol=1e-5)
+    loss, gn, _ = O.train_step(x, mask, P, cfg)
+    assert loss == pytest.approx(float(g["losses"][0]), rel=1e-5) and gn == pytest.approx(float(g["grad_norms"][0]), rel=1e-4)
+
+
 # ----------------------------------------------------------------------------- BASELINE config[0]: the engine itself
 def test_vitb_engine_step_parity():
     """Fixture = the reference's own train_one_epoch, one step, ViT-B, B=2, tube masks (seeds 10 and 0)."""
