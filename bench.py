@@ -73,52 +73,6 @@ def cpu_baseline(seconds_budget: float):
             "sample": f"oracle fp32 torch-CPU train step, ViT-B dec4, batch 2, {n} timed steps after 1 warm-up ({dt:.1f} s)"}
 
 
-def eager_gpu_baseline(B: int, steps: int = 10):
-    """--eager-gpu-baseline (opt-in, not part of the default line): what the reference's step costs under PyTorch on THIS GPU -- the
-    oracle's functional restatement routed through the torch library ops the reference's modules call (O.LIBRARY_OPS: F.linear,
-    F.layer_norm, F.gelu, softmax, boolean-mask gathers; attention as q @ k^T -> softmax -> @ v, modeling_finetune.py:85-95) under a
-    bf16 autocast (the reference: fp16 autocast + GradScaler, engine_for_pretraining.py:65), torch.optim.AdamW, the per-tensor norm loop
-    of utils.py:376-388 and the two syncs of engine_for_pretraining.py:69,179.  ViT-B, B clips, same synthetic shapes as the timed step."""
-    from oracle import pretrain_oracle as O
-    dev = torch.device("cuda:0")
-    cfg = O.VIT_B
-    O.LIBRARY_OPS = True
-    try:
-        P = {k: v.to(dev).requires_grad_(True) for k, v in O.keyed_params(cfg, "xavier").items()}
-        dec = [p for k, p in P.items() if not O.is_no_decay(k, p.shape)]
-        nod = [p for k, p in P.items() if O.is_no_decay(k, p.shape)]
-        opt = torch.optim.AdamW([{"params": dec, "weight_decay": 0.05}, {"params": nod, "weight_decay": 0.0}], lr=1.5e-4, betas=(0.9, 0.95), eps=1e-8)
-        x = torch.randn(B, 3, cfg.num_frames, cfg.img_size, cfg.img_size, device=dev)
-        np.random.seed(0)
-        mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.9) for _ in range(B)])).bool().to(dev)
-
-        def step():
-            with torch.no_grad():
-                labels = O.build_targets(x, mask, cfg, True)
-            with torch.autocast("cuda", dtype=torch.bfloat16):
-                out = O.model_forward(x, mask, P, cfg)
-                loss = O.mse_loss(out, labels)
-            v = loss.item()
-            opt.zero_grad()
-            loss.backward()
-            torch.norm(torch.stack([torch.norm(p.grad.detach(), 2.0) for p in P.values()]), 2.0)
-            opt.step()
-            torch.cuda.synchronize()
-            return v
-        for _ in range(3):
-            step()
-        torch.cuda.synchronize()
-        t0 = time.time()
-        for _ in range(steps):
-            last = step()
-        torch.cuda.synchronize()
-        dt = time.time() - t0
-    finally:
-        O.LIBRARY_OPS = False
-    return {"value": round(B * steps / dt, 2), "unit": "clips/s", "ms_per_step": round(1e3 * dt / steps, 3), "kind": "port", "final_loss": round(last, 5),
-            "sample": f"oracle restatement through torch library ops, bf16 autocast, torch.optim.AdamW, ViT-B batch {B}, {steps} timed steps on cuda:0"}
-
-
 def self_launch(n: int) -> int:
     """run `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process and relay its output"""
     import socket
@@ -157,8 +111,6 @@ def main():
     ap.add_argument("--input", choices=["f32", "uint8"], default="f32",
                     help="f32: the model's input contract (normalised clips in HBM); uint8: the loader's frame stack [B,H,W,T*3], "
                          "normalised inside the gather / target kernels (side measurement)")
-    ap.add_argument("--eager-gpu-baseline", action="store_true", help="also time the reference's step as plain PyTorch on this GPU (oracle through torch "
-                                                                        "library ops, bf16 autocast); adds eager_gpu_baseline to the line")
     ap.add_argument("--fp8", action="store_true", help="side measurement (BASELINE configs[4]): the four forward Linears of every block (qkv, proj, fc1, "
                                                        "fc2) on OCP e4m3 operands with the block-scaled MFMA; attention and the backward bf16")
     ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
@@ -517,11 +469,6 @@ def main():
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.cpu_seconds)
-        if world == 1 and args.eager_gpu_baseline and args.model == "vitb16":
-            del model, opt, wrapped
-            torch.cuda.empty_cache()
-            out["eager_gpu_baseline"] = eager_gpu_baseline(B)
-            out["eager_gpu_baseline"]["speedup_of_value"] = round(out["value"] / out["eager_gpu_baseline"]["value"], 2)
         print(json.dumps(out), flush=True)
     if world > 1 or force_dp:
         dist.destroy_process_group()

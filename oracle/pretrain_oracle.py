@@ -222,7 +222,7 @@ def ingest_uint8(frames: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- forward pieces
-# LIBRARY_OPS (bench.py's eager baseline only): the same forward through the torch library ops the reference's nn.Modules call
+# LIBRARY_OPS (tests/eager_gpu_baseline.py only): the same forward through the torch library ops the reference's nn.Modules call
 # (F.linear / F.layer_norm / F.gelu / softmax) instead of the elementary ops below -- what "the reference under PyTorch" costs on a
 # device, not a different arithmetic (tests/test_oracle_golden.py holds the two forms together on CPU).  Works on any device.
 LIBRARY_OPS = False

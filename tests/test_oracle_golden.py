@@ -134,7 +134,7 @@ def test_tiny_full_parity(mode):
 
 
 def test_library_ops_form_is_the_same_arithmetic(monkeypatch):
-    """O.LIBRARY_OPS (bench.py's eager baseline) routes the forward through F.linear / F.layer_norm / F.gelu / softmax: the fixture's output
+    """O.LIBRARY_OPS (tests/eager_gpu_baseline.py) routes the forward through F.linear / F.layer_norm / F.gelu / softmax: the fixture's output
     and first-step loss / gradient norm to the tolerances the elementary form is held to"""
     g = _load("tiny_small.npz")
     cfg = O.TINY
