@@ -179,6 +179,21 @@ def test_fp8_quantisation_kernels(dev):
     assert torch.equal(y, y2)
     assert torch.equal(y8.view(torch.uint8), (y.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))
     assert float(ams.max()) == float(y.float().abs().max())             # EVERY row contributes (an outlier row cannot be missed)
+    # ... and the two-rows-per-wave form of the bf16 residual stream (the decoder), odd row count, narrower than a wave's 512 columns
+    for M2, D2 in ((513, 384), (1025, 512), (7, 128)):
+        xb = _rand((M2, D2), dev, 6, 2.0)
+        w2 = _rand((D2,), dev, 7, 0.3, F32) + 1.0
+        b2 = _rand((D2,), dev, 8, 0.3, F32)
+        ya, yb = torch.empty(M2, D2, dtype=BF16, device=dev), torch.empty(M2, D2, dtype=BF16, device=dev)
+        m2, r2 = torch.empty(M2, dtype=F32, device=dev), torch.empty(M2, dtype=F32, device=dev)
+        m3, r3 = torch.empty(M2, dtype=F32, device=dev), torch.empty(M2, dtype=F32, device=dev)
+        y8b = torch.zeros(M2, D2, dtype=F8, device=dev)
+        ams2 = torch.zeros(ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
+        ops.layernorm_fwd_q(xb, w2, b2, 1e-6, ya, m2, r2, y8b, sc, ams2)
+        ops.layernorm_fwd(xb, w2, b2, 1e-6, yb, m3, r3)
+        assert torch.equal(ya, yb) and torch.equal(m2, m3) and torch.equal(r2, r3)
+        assert torch.equal(y8b.view(torch.uint8), (ya.float() * 20.0).clamp(-448, 448).to(F8).view(torch.uint8))
+        assert float(ams2.max()) == float(ya.float().abs().max())
     # delayed scaling update: a site's stripes are folded, then cleared
     amx = torch.zeros(2, ops.FP8_AMAX_STRIPES, dtype=F32, device=dev)
     amx[0, 5], amx[0, 700] = 1.5, 2.0
