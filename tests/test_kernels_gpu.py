@@ -128,6 +128,9 @@ def test_gemm_nt_fp8(dev, M, N, K):
         want = ref + bias + Rbig.view(4, rout, N)[:, roff:roff + rin].reshape(M, N).float()
         ops.gemm(ops.GEMM_NT_FP8, ops.EPI_RESID_BF16, A8, W8, C, bias=bias, aux=Rbig, rows_in=rin, rows_out=rout, row_off=roff, a_scale_inv=ai, b_scale_inv=wi)
         assert _rel(C, want) < 5e-3
+        Rbig32 = Rbig.float().contiguous()
+        ops.gemm(ops.GEMM_NT_FP8, ops.EPI_RESID_F32, A8, W8, Cf, bias=bias, resid=Rbig32, rows_in=rin, rows_out=rout, row_off=roff, a_scale_inv=ai, b_scale_inv=wi)
+        assert _rel(Cf, want) < 1e-4
     # the quantisation itself: against the unquantised product the error is e4m3's (3 mantissa bits on both operands)
     assert _rel(ref, a @ w.t()) < 6e-2
     with pytest.raises(RuntimeError, match="multiple of 128"):
