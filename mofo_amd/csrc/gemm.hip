@@ -121,7 +121,7 @@ __device__ __forceinline__ void srd_lane_offsets(int ld, int lane, int& v0, int&
 // order, so unknown extra operations in the queue only make its `vmcnt(N)` wait for more.
 // M0 (the LDS destination base) is saved and restored inside the statement (hipcc reserves it); `s_nop 4` covers a descriptor /
 // offset SGPR freshly written by a VALU (v_readfirstlane); `s_nop 0` the M0 write -> LDS-DMA hazard.
-// Measured (profiles/r05_dma_asm_ab.txt): the ring kernel's weight gradients 869 -> 1 064 TFLOP/s at 4096^3 with the asm form; gemm_k2's
+// Measured (profiles/r05_gemm_r3_ab.txt, r05_dma_asm_k2.txt): the ring kernel's weight gradients 869 -> 1 064 TFLOP/s at 4096^3 with the asm form; gemm_k2's
 // NN shapes are 10 % SLOWER with it (its inserted wait only shortens a two-stage ring, and an asm statement is a scheduling barrier
 // the builtin is not), so gemm_k2 and gemm8 keep the builtin (MOFO_DMA_ASM_K2 / _G8 = 1 builds them with the asm form).
 // LEAN: M0 is not saved / restored and no VALU -> SGPR pad is issued -- for kernels that contain no compiler-visible use of M0 and
