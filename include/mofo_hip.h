@@ -22,7 +22,9 @@ extern "C" {
  * mofo_gemm_grouped takes up to 32 weight-gradient problems; INTEGRATION.md lists every change of the exported set. */
 /* 3 (round 5): mofo_gemm_args grew (C8, ldc8, q_scale, q_amax: the e4m3 copy of fc1's activation); MOFO_GEMM_NT_FP8 takes the
  * residual epilogues; new entries mofo_attention_fwd_q8, mofo_adamw_q8. */
-#define MOFO_ABI_VERSION 3
+/* 4 (round 6): new entries mofo_gemm_wgrad_sliced / mofo_gemm_wgrad_sliced_ws (the weight gradients of a whole pass in ONE launch, the token
+ * reduction sliced over the XCDs, no atomics); mofo_gemm_route_counts reports a ninth family (the 384 x 128 ring kernel). */
+#define MOFO_ABI_VERSION 4
 
 /* ---- library ---- */
 int mofo_version(void);
@@ -84,9 +86,22 @@ int mofo_gemm_grouped(const mofo_gemm_args* args, int count, void* stream);
  * plainly stored exactly once.  Returns 1 when the group goes to the ring kernel, 0 otherwise, < 0 on error.  Same routing
  * decision as mofo_gemm_grouped with the same arguments and environment. */
 int mofo_gemm_grouped_plan(const mofo_gemm_args* args, int count, int* shared);
+/* SLICED weight-gradient group: the autograd of the Linears of modeling_finetune.py:44-51,84,96 at the decoder widths of
+ * modeling_pretrain.py:292-314, where the reduction runs over all B * 1568 token rows.  Up to 32 problems, every one TN + F32
+ * (C[m,n] (+)= sum_k A[k,m] B[k,n]; colsum as in mofo_gemm_grouped; bias = NULL; splits <= 1; all problems agree on accumulate).
+ * The reduction of EVERY problem is cut into `slices` (1..8) contiguous row ranges; slice s of all problems is computed by the
+ * workgroups of one XCD label (blockIdx % 8 == s for 8 slices), which therefore streams one row range of the operands through its
+ * L2: every operand byte is fetched by one XCD only.  The slices' partial products are plainly stored to the caller's workspace
+ * `ws` (mofo_gemm_wgrad_sliced_ws(...) floats, 16-byte aligned; contents undefined afterwards) and a second kernel of the same call
+ * sums them into C (overwrite, or += when accumulate != 0): NO destination needs zeroing and no float atomics touch C, so results
+ * are bit-identical from launch to launch.  Tile: 384 x 128 (gemm_r4) when every M is a multiple of 384 and every N of 128, else
+ * 256 x 128 (ragged tiles allowed).  Slice s of a problem is rows [s k, (s + 1) k) with k = ceil(K / slices) rounded up to 32.
+ * mofo_gemm_wgrad_sliced_ws returns the workspace size in floats (< 0: error code). */
+long long mofo_gemm_wgrad_sliced_ws(const mofo_gemm_args* args, int count, int slices);
+int mofo_gemm_wgrad_sliced(const mofo_gemm_args* args, int count, int slices, float* ws, long long ws_floats, void* stream);
 /* Diagnostics (host side, no device work): launches per main-loop family since the last reset -- out[0] one tile per block,
  * [1] persistent 64/128-row tiles, [2] persistent 256-row tiles, [3] in-block split-K, [4] the 256 x 256 counted-vmcnt kernel,
- * [5] e4m3, [6] one 128 x 128 tile per CU with the reduction halved over two wave groups, [7] the 256 x 128 three-stage ring kernel.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
+ * [5] e4m3, [6] one 128 x 128 tile per CU with the reduction halved over two wave groups, [7] the 256 x 128 three-stage ring kernel, [8] the 384 x 128 four-stage ring kernel.  Lets a parity test assert that the shape-routed form it is meant to cover really ran. */
 int mofo_gemm_route_counts(long long* out, int n, int reset);
 
 /* ---- column sums: bias gradients (autograd of the `+ bias` in the Linears above). out[n] (+)= sum_m X[m,n] ---- */

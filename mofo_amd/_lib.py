@@ -37,6 +37,8 @@ _SIGS = {
     "mofo_gemm_grouped": (_i, [C.POINTER(GemmArgs), _i, _vp]),
     "mofo_gemm_grouped_plan": (_i, [C.POINTER(GemmArgs), _i, C.POINTER(_i)]),
     "mofo_gemm_route_counts": (_i, [C.POINTER(_ll), _i, _i]),
+    "mofo_gemm_wgrad_sliced_ws": (_ll, [C.POINTER(GemmArgs), _i, _i]),
+    "mofo_gemm_wgrad_sliced": (_i, [C.POINTER(GemmArgs), _i, _i, _vp, _ll, _vp]),
     "mofo_colsum_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp]),
     "mofo_layernorm_fwd": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
     "mofo_layernorm_fwd_q": (_i, [_vp, _i, _i, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp]),
@@ -106,7 +108,7 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
-        if lib.mofo_version() != 3:
+        if lib.mofo_version() != 4:
             raise RuntimeError("libmofo_hip.so ABI version mismatch")
         _lib = lib
     return _lib

@@ -31,7 +31,7 @@ def _stale(target, deps):
 
 
 def build(force=False, verbose=False):
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "gemm_k2.h"), os.path.join(CSRC, "gemm_r3.h"), os.path.join(HERE, "..", "include", "mofo_hip.h"), os.path.abspath(__file__)]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm8.h"), os.path.join(CSRC, "gemm_k2.h"), os.path.join(CSRC, "gemm_r3.h"), os.path.join(CSRC, "gemm_r4.h"), os.path.join(HERE, "..", "include", "mofo_hip.h"), os.path.abspath(__file__)]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     jobs = []

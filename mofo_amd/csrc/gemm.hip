@@ -1047,6 +1047,7 @@ __global__ __launch_bounds__(256, 3) void gemm_fp8_persistent_kernel(GemmP p, in
 #include "gemm8.h"
 #include "gemm_k2.h"
 #include "gemm_r3.h"
+#include "gemm_r4.h"
 
 // Which main-loop form per (layouts, epilogue, grid), from A/B timing of kernel classes inside the ViT-B B=32 step on MI355X
 // (MOFO_GEMM_VARIANT=0|1|2 forces one form; profiles/):
@@ -1082,7 +1083,7 @@ static bool gemm8_has(int op, int epi) {
 
 // launches per kernel family since the last reset (mofo_gemm_route_counts): tests assert that a model-level parity run really went
 // through the shape-routed forms it is meant to cover
-enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_K2 = 6, ROUTE_R3 = 7, ROUTE_N = 8 };
+enum { ROUTE_TILE = 0, ROUTE_PERSIST = 1, ROUTE_PERSIST8 = 2, ROUTE_KSPLIT = 3, ROUTE_GEMM8 = 4, ROUTE_FP8 = 5, ROUTE_K2 = 6, ROUTE_R3 = 7, ROUTE_R4 = 8, ROUTE_N = 9 };
 static long long g_route[ROUTE_N];
 #define ROUTE(k) __atomic_fetch_add(&g_route[k], 1LL, __ATOMIC_RELAXED)
 
@@ -1328,18 +1329,18 @@ static bool r3_legal(const mofo_gemm_args* a, int count) {
 //   1 block 0.84 rounds: 0.94-0.98 x | 2 blocks 1.69: 1.12-1.22 x | 3 blocks 2.53: 0.94-0.97 x | 6 blocks 5.06 with the tail dealt in
 //   chunks: 1.02 x | 7 blocks 5.91: 1.04 x (the 128 x 128 kernel takes at most three blocks per launch)
 // Whole tiles only: the decoder's 384-wide outputs pad 256-row tiles by 14 % (0.65-0.92 x, not routed).
-static bool r3_rounds(const mofo_gemm_args* a, int count, double* rounds) {
+static bool r3_rounds(const mofo_gemm_args* a, int count, double* rounds, int tm = 256) {
     long long units = 0;
     for (int i = 0; i < count; ++i) {
-        if (a[i].M % R3_TM || a[i].N % R3_TN || a[i].K < 2048) return false;
-        units += (long long)(a[i].M / R3_TM) * (a[i].N / R3_TN) * (a[i].splits < 1 ? 1 : a[i].splits);
+        if (a[i].M % tm || a[i].N % 128 || a[i].K < 2048) return false;
+        units += (long long)(a[i].M / tm) * (a[i].N / 128) * (a[i].splits < 1 ? 1 : a[i].splits);
     }
     *rounds = (double)units / 256.0;
     return true;
 }
-static bool r3_wanted(const mofo_gemm_args* a, int count) {
+static bool r3_wanted(const mofo_gemm_args* a, int count, int tm = 256) {
     double r;
-    if (!r3_rounds(a, count, &r)) return false;
+    if (!r3_rounds(a, count, &r, tm)) return false;
     const int fl = (int)r;
     const double frac = r - fl;
     if (fl >= 4) return true;                                 // many rounds: at most one in five is partly filled, or its units are dealt in chunks
@@ -1347,9 +1348,9 @@ static bool r3_wanted(const mofo_gemm_args* a, int count) {
 }
 // the last, partial round of a run is dealt in chunks (f32 atomics onto zeroed destinations) only when it is a small share of the
 // launch: every unit of it costs its sharers an atomic pass over its 128 KiB (1.3 TB/s chip-wide; 1 block: 0.52 x, 6 blocks: 1.02 x)
-static int r3_tail_auto(const mofo_gemm_args* a, int count) {
+static int r3_tail_auto(const mofo_gemm_args* a, int count, int tm = 256) {
     double r;
-    if (!r3_rounds(a, count, &r)) return 0;
+    if (!r3_rounds(a, count, &r, tm)) return 0;
     const int fl = (int)r;
     return fl >= 4 && r - fl > 0.0 && r - fl <= 0.2;
 }
@@ -1357,13 +1358,22 @@ static int r3_mode() {
     const char* e = getenv("MOFO_GEMM_R3");      // read per call: A/B switches inside one process
     return e ? atoi(e) : -1;
 }
-static int r3_fill(const mofo_gemm_args* a, int count, R3Group& g) {
+// tile rows of the ring kernel a weight-gradient group goes to: 384 (gemm_r4.h) under MOFO_GEMM_R4=1 when every output is whole
+// 384 x 128 tiles, else 256 (gemm_r3.h)
+static int ring_tm(const mofo_gemm_args* a, int count) {
+    const char* e = getenv("MOFO_GEMM_R4");      // read per call: A/B switches inside one process
+    if (!e || atoi(e) != 1) return R3_TM;
+    for (int i = 0; i < count; ++i)
+        if (a[i].M % R4_TM || a[i].N % R3_TN) return R3_TM;
+    return R4_TM;
+}
+static int r3_fill(const mofo_gemm_args* a, int count, R3Group& g, int tm = R3_TM) {
     g.count = count;
     g.start[0] = 0;
     for (int i = 0; i < count; ++i) {
         GemmP full;
         int blocks = 0;
-        const int rc = fill_problem(&a[i], full, R3_TM, R3_TN, blocks);
+        const int rc = fill_problem(&a[i], full, tm, R3_TN, blocks);
         if (rc) return rc;
         R3Prob& p = g.p[i];
         p.A = full.A; p.B = full.B; p.C = full.C; p.colsum = full.colsum;
@@ -1376,7 +1386,9 @@ static int r3_fill(const mofo_gemm_args* a, int count, R3Group& g) {
         g.start[i + 1] = g.start[count];
     }
     const char* e = getenv("MOFO_GEMM_R3_TAIL");     // 0 / 1 forces plain rounds / tail chunks (tests, A/B); unset: by shape
-    g.tail = e ? atoi(e) : r3_tail_auto(a, count);
+    g.tail = e ? atoi(e) : r3_tail_auto(a, count, tm);
+    g.slices = 0;
+    g.slab_stride = 0;
     return MOFO_OK;
 }
 static int r3_grid() {
@@ -1414,12 +1426,118 @@ static int r3_launch(const mofo_gemm_args* a, int count, hipStream_t s) {
     return MOFO_OK;
 }
 
+// ---- the 384 x 128 ring kernel (gemm_r4.h) and the SLICED weight-gradient launch.
+// MOFO_GEMM_R4 = 1: weight-gradient groups whose outputs are whole 384 x 128 tiles go to gemm_r4 instead of gemm_r3 (plain rounds /
+// tail chunks as r3_fill decides); unset / 0: gemm_r4 runs only behind mofo_gemm_wgrad_sliced.
+static bool r4_tiles(const mofo_gemm_args* a, int count) {
+    for (int i = 0; i < count; ++i)
+        if (a[i].M % R4_TM || a[i].N % R3_TN) return false;
+    return true;
+}
+static int r4_launch(const mofo_gemm_args* a, int count, hipStream_t s) {
+    R3Group g;
+    const int rc = r3_fill(a, count, g, R4_TM);
+    if (rc) return rc;
+    hipLaunchKernelGGL((gemm_r4_kernel<MOFO_EPI_F32>), dim3(r3_grid()), dim3(512), 0, s, g, g.start[count]);
+    ROUTE(ROUTE_R4);
+    MOFO_CHECK_LAUNCH("mofo_gemm(r4)");
+    return MOFO_OK;
+}
+
+// SLICED weight gradients (include/mofo_hip.h: mofo_gemm_wgrad_sliced).  tile rows: 384 when every output is whole 384 x 128 tiles
+// (MOFO_WGRAD_TILE=256 forces gemm_r3's 256-row tiles: A/B), else 256 (ragged tiles allowed).
+static int sliced_tile(const mofo_gemm_args* a, int count) {
+    const char* e = getenv("MOFO_WGRAD_TILE");
+    if (e && atoi(e) == 256) return R3_TM;
+    return r4_tiles(a, count) ? R4_TM : R3_TM;
+}
+static int sliced_check(const mofo_gemm_args* a, int count, int slices, long long* stride) {
+    if (!a || count < 1 || count > MAXR) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_wgrad_sliced: count must be 1..%d", MAXR);
+    if (slices < 1 || slices > 8) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_wgrad_sliced: slices must be 1..8");
+    long long tot = 0;
+    for (int i = 0; i < count; ++i) {
+        if (a[i].op != MOFO_GEMM_TN || a[i].epilogue != MOFO_EPI_F32 || a[i].bias || a[i].splits > 1)
+            MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm_wgrad_sliced: every problem must be TN + F32 without bias / splits");
+        if (a[i].M <= 0 || a[i].N <= 0 || a[i].K <= 0 || a[i].N % 8) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_wgrad_sliced: bad dims");
+        tot += (long long)a[i].M * a[i].N;
+    }
+    *stride = tot;
+    return MOFO_OK;
+}
+extern "C" long long mofo_gemm_wgrad_sliced_ws(const mofo_gemm_args* a, int count, int slices) {
+    long long stride = 0;
+    const int rc = sliced_check(a, count, slices, &stride);
+    if (rc) return rc;
+    return stride * slices;
+}
+extern "C" int mofo_gemm_wgrad_sliced(const mofo_gemm_args* a, int count, int slices, float* ws, long long ws_floats, void* stream) {
+    long long stride = 0;
+    int rc = sliced_check(a, count, slices, &stride);
+    if (rc) return rc;
+    if (!ws || ws_floats < stride * slices || ((uintptr_t)ws & 15))
+        MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_wgrad_sliced: workspace of %lld floats (16-byte aligned) needed, got %lld", stride * slices, ws_floats);
+    hipStream_t s = (hipStream_t)stream;
+    const int tm = sliced_tile(a, count);
+    R3Group g;
+    SlabReduceP rp;
+    g.count = count;
+    g.start[0] = 0;
+    rp.start[0] = 0;
+    long long off = 0;
+    int accumulate = -1;
+    for (int i = 0; i < count; ++i) {
+        GemmP full;
+        int blocks = 0;
+        mofo_gemm_args one = a[i];
+        one.splits = 1;
+        one.accumulate = 0;
+        rc = fill_problem(&one, full, tm, R3_TN, blocks);
+        if (rc) return rc;
+        if (a[i].ldc % 4 || ((uintptr_t)a[i].C & 15)) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_gemm_wgrad_sliced: C must be 16-byte aligned with ldc a multiple of 4");
+        if (accumulate >= 0 && accumulate != (a[i].accumulate ? 1 : 0)) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_wgrad_sliced: problems must agree on accumulate");
+        accumulate = a[i].accumulate ? 1 : 0;
+        R3Prob& p = g.p[i];
+        p.A = full.A; p.B = full.B; p.colsum = full.colsum;
+        p.C = ws + off;                     // slab 0 of this problem, dense rows of N
+        p.M = full.M; p.N = full.N; p.K = full.K; p.lda = full.lda; p.ldb = full.ldb; p.ldc = full.N;
+        p.k_per_split = ceil_div(ceil_div(full.K, slices), R4_KH) * R4_KH;     // (a slice past the end of a short reduction stores zeros)
+        p.atomic = 0; p.skip_lo = full.colsum_skip_lo; p.skip_hi = full.colsum_skip_hi;
+        g.start[i + 1] = g.start[i] + blocks;
+        rp.C[i] = (float*)a[i].C; rp.off[i] = off; rp.M[i] = a[i].M; rp.N[i] = a[i].N; rp.ldc[i] = a[i].ldc;
+        rp.start[i + 1] = rp.start[i] + (int)(((long long)a[i].M * a[i].N / 4 + 255) / 256);
+        off += (long long)a[i].M * a[i].N;
+    }
+    for (int i = count; i < MAXR; ++i) {
+        g.p[i] = g.p[0];
+        g.start[i + 1] = g.start[count];
+        rp.C[i] = rp.C[0]; rp.off[i] = 0; rp.M[i] = 0; rp.N[i] = 8; rp.ldc[i] = 8;
+        rp.start[i + 1] = rp.start[count];
+    }
+    g.tail = 0;
+    g.slices = slices;
+    g.slab_stride = stride;
+    const int total = slices * g.start[count];
+    if (tm == R4_TM) {
+        hipLaunchKernelGGL((gemm_r4_kernel<MOFO_EPI_F32>), dim3(r3_grid()), dim3(512), 0, s, g, total);
+        ROUTE(ROUTE_R4);
+    } else {
+        hipLaunchKernelGGL((gemm_r3_kernel<OPL_COL, OPL_COL, MOFO_EPI_F32>), dim3(r3_grid()), dim3(512), 0, s, g, total);
+        ROUTE(ROUTE_R3);
+    }
+    MOFO_CHECK_LAUNCH("mofo_gemm_wgrad_sliced(ring)");
+    rp.count = count; rp.slices = slices; rp.accumulate = accumulate; rp.slab_stride = stride; rp.ws = ws;
+    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(rp.start[count]), dim3(256), 0, s, rp);
+    MOFO_CHECK_LAUNCH("mofo_gemm_wgrad_sliced(reduce)");
+    return MOFO_OK;
+}
+
 extern "C" int mofo_gemm_grouped_plan(const mofo_gemm_args* a, int count, int* shared) {
     if (!a || !shared || count < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped_plan: null argument");
     const int mode = r3_mode();
-    if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count))) {
+    const int tm = ring_tm(a, count);
+    if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count, tm))) {
         R3Group g;
-        const int rc = r3_fill(a, count, g);
+        const int rc = r3_fill(a, count, g, tm);
         if (rc) return rc;
         r3_plan(g, r3_grid(), shared);
         return 1;
@@ -1432,7 +1550,9 @@ extern "C" int mofo_gemm_grouped(const mofo_gemm_args* a, int count, void* strea
     if (!a || count < 1) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d", MAXG);
     {
         const int mode = r3_mode();
-        if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count))) return r3_launch(a, count, (hipStream_t)stream);
+        const int tm = ring_tm(a, count);
+        if (mode != 0 && r3_legal(a, count) && (mode == 1 || r3_wanted(a, count, tm)))
+            return tm == R4_TM ? r4_launch(a, count, (hipStream_t)stream) : r3_launch(a, count, (hipStream_t)stream);
     }
     if (count > MAXG) MOFO_FAIL(MOFO_EINVAL, "mofo_gemm_grouped: count must be 1..%d (1..%d for weight-gradient groups on the 256 x 128 ring kernel)", MAXG, MAXR);
     GroupP g;

@@ -60,9 +60,16 @@ struct R3Prob {
 };
 struct R3Group {
     R3Prob p[MAXR];
-    int start[MAXR + 1];       // first unit of each problem; start[count] = units of the launch
+    int start[MAXR + 1];       // first unit of each problem; start[count] = units of the launch (SLICED: of one slice)
     int count;
     int tail;                  // 1: cut the last partial round of every XCD run into chunks (else: plain rounds)
+    // SLICED (slices > 0; mofo_gemm_wgrad_sliced): the list is SLICE-major -- unit w = (slice w / U, problem, tile) with U = start[count]
+    // -- and slice s of EVERY problem is reduction rows [s k_per_split, (s + 1) k_per_split).  With slices = 8 the XCD label x = blockIdx & 7
+    // owns exactly slice x: all the rounds of an XCD stream ONE row range of the operands through its L2 (each operand byte is fetched
+    // by one XCD only), and a round's 32 units are neighbouring tiles of one or two problems in k-lock-step.  Results are PARTIAL sums:
+    // plainly stored to slab `slice` of a workspace (p.C + slice * slab_stride, dense rows of N), summed by wgrad_slab_reduce_kernel.
+    int slices;
+    long long slab_stride;     // f32 elements between two slices' slabs
 };
 
 struct R3Seg {
@@ -70,30 +77,44 @@ struct R3Seg {
     int k0, kend;              // first reduction row of the segment; end of the UNIT's reduction range (operand extent for the range check)
     int nk;                    // k-steps of the segment
     int atomic;
+    int slice;                 // SLICED: which slab the result goes to (else 0)
 };
 
-// unit `wg` (index into the launch's (problem, split, tile) list) -> its whole-unit segment
-__device__ __forceinline__ R3Seg r3_unit(const R3Group& G, int wg) {
+// unit `wg` (index into the launch's (problem, split, tile) list) -> its whole-unit segment.  TM: tile rows (256: gemm_r3, 384: gemm_r4);
+// KS: reduction rows per k-step of the kernel's ring (64 / 32)
+template <int TM, int KS>
+__device__ __forceinline__ R3Seg ring_unit(const R3Group& G, int wg) {
+    int slice = 0;
+    if (G.slices > 0) {
+        const int U = G.start[G.count];
+        slice = wg / U;
+        wg -= slice * U;
+    }
     int gi = 0;
 #pragma nounroll
     for (int k = 1; k < G.count; ++k)
         if (wg >= G.start[k]) gi = k;
     const R3Prob& p = G.p[gi];
-    const int tiles_n = (p.N + R3_TN - 1) / R3_TN, tiles_m = (p.M + R3_TM - 1) / R3_TM;
+    const int tiles_n = (p.N + R3_TN - 1) / R3_TN, tiles_m = (p.M + TM - 1) / TM;
     const int tiles = tiles_n * tiles_m;
     wg -= G.start[gi];
-    const int split = wg / tiles;
-    wg -= split * tiles;
+    int split = slice;
+    if (G.slices <= 0) {
+        split = wg / tiles;
+        wg -= split * tiles;
+    }
     R3Seg s;
     s.gi = gi;
-    s.m0 = (tiles_n <= tiles_m ? wg / tiles_n : wg % tiles_m) * R3_TM;
+    s.m0 = (tiles_n <= tiles_m ? wg / tiles_n : wg % tiles_m) * TM;
     s.n0 = (tiles_n <= tiles_m ? wg % tiles_n : wg / tiles_m) * R3_TN;
     s.k0 = split * p.k_per_split;
     s.kend = min(p.K, s.k0 + p.k_per_split);
-    s.nk = (s.kend - s.k0 + BK - 1) / BK;
+    s.nk = s.kend > s.k0 ? (s.kend - s.k0 + KS - 1) / KS : 0;
     s.atomic = p.atomic;
+    s.slice = slice;
     return s;
 }
+__device__ __forceinline__ R3Seg r3_unit(const R3Group& G, int wg) { return ring_unit<R3_TM, BK>(G, wg); }
 
 template <int LA, int LB, int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
@@ -375,7 +396,7 @@ __global__ __launch_bounds__(512, 2) void gemm_r3_kernel(R3Group G, int total) {
         // 256-B row segments (plain stores, or one 256-B row per f32 atomic instruction for a shared / split / accumulating unit)
         {
             GemmP pe = {};
-            pe.C = p.C;
+            pe.C = (float*)p.C + (long long)cs.slice * G.slab_stride;
             pe.M = p.M;
             pe.N = p.N;
             pe.ldc = p.ldc;

@@ -224,13 +224,34 @@ def _gemm_args(op, epi, A, B, C_, *, C2=None, bias=None, resid=None, aux=None, p
     return a, 2.0 * M * N * K, nbytes
 
 
-GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8", "k2", "r3")
+def gemm_wgrad_sliced_ws(problems, slices=8):
+    """f32 elements of workspace ``gemm_wgrad_sliced`` needs for these weight-gradient problems"""
+    built = [_gemm_args(GEMM_TN, EPI_F32, A, B, C_, **kw) for A, B, C_, kw in problems]
+    arr = (GemmArgs * len(built))(*[b[0] for b in built])
+    n = _lib.load().mofo_gemm_wgrad_sliced_ws(arr, len(built), slices)
+    if n < 0:
+        _lib.check(int(n), "mofo_gemm_wgrad_sliced_ws")
+    return int(n)
+
+
+def gemm_wgrad_sliced(problems, ws, slices=8):
+    """a group of weight gradients C (+)= A^T B (TN, f32; fused bias-gradient column sums) with the token reduction cut into
+    ``slices`` row ranges, one per XCD: partial sums go to ``ws`` with plain stores (no destination needs zeroing, no atomics),
+    a second kernel sums the slices into C (include/mofo_hip.h: mofo_gemm_wgrad_sliced)"""
+    _chk(ws, F32, "ws", 1)
+    built = [_gemm_args(GEMM_TN, EPI_F32, A, B, C_, **kw) for A, B, C_, kw in problems]
+    arr = (GemmArgs * len(built))(*[b[0] for b in built])
+    _run("mofo_gemm_wgrad_sliced", ("gemm", GEMM_TN, EPI_F32), (sum(b[1] for b in built), sum(b[2] for b in built)),
+         arr, len(built), slices, ws.data_ptr(), ws.numel())
+
+
+GEMM_ROUTES = ("tile", "persistent", "persistent256", "ksplit", "gemm8", "fp8", "k2", "r3", "r4")
 
 
 def gemm_route_counts(reset=False):
     """launches per GEMM main-loop family since the last reset (include/mofo_hip.h: mofo_gemm_route_counts)"""
-    buf = (C.c_longlong * 8)()
-    _lib.check(_lib.load().mofo_gemm_route_counts(buf, 8, 1 if reset else 0), "mofo_gemm_route_counts")
+    buf = (C.c_longlong * len(GEMM_ROUTES))()
+    _lib.check(_lib.load().mofo_gemm_route_counts(buf, len(GEMM_ROUTES), 1 if reset else 0), "mofo_gemm_route_counts")
     return {name: int(buf[i]) for i, name in enumerate(GEMM_ROUTES)}
 
 

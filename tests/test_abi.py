@@ -24,7 +24,7 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/mofo_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names, "ctypes table and header disagree"
-    assert lib.mofo_version() == 3
+    assert lib.mofo_version() == 4
 
 
 def test_library_is_in_tree_and_hip_only():

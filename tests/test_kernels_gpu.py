@@ -586,6 +586,124 @@ def test_gemm_r3_ring_family(dev, monkeypatch, R, P, Q, grid, tail):
     assert ops.gemm_route_counts()["r3"] >= 3 and ops.gemm_route_counts()["tile"] == 0
 
 
+@pytest.mark.parametrize("grid,tail", [("16", "1"), ("256", "1"), ("24", "0")])
+@pytest.mark.parametrize("R,P,Q", [(96, 384, 128), (320, 768, 384), (1000, 384, 256), (2888, 1152, 384), (4100, 1536, 384), (40, 384, 1536)])
+def test_gemm_r4_ring_family(dev, monkeypatch, R, P, Q, grid, tail):
+    """The 384 x 128 four-stage ring kernel (csrc/gemm_r4.h: 32-deep stages, counted vmcnt, single-buffered A fragments, one barrier
+    per stage), forced with MOFO_GEMM_R3=1 + MOFO_GEMM_R4=1 on weight-gradient (TN, f32) problems whose outputs are whole 384 x 128
+    tiles: reductions of 1, 2, 3 (mod 4) stages and not a multiple of 32, split-K, accumulate, the fused bias-gradient column sums
+    with a skipped range, a grouped launch with three reduction lengths; grids as in test_gemm_r3_ring_family (rounds + tail chunks,
+    all tail, plain rounds).  Element-wise against fp32 torch; destinations the plan does not flag are poisoned with NaN first."""
+    from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM_R3", "1")
+    monkeypatch.setenv("MOFO_GEMM_R4", "1")
+    monkeypatch.setenv("MOFO_GEMM_R3_GRID", grid)
+    monkeypatch.setenv("MOFO_GEMM_R3_TAIL", tail)
+
+    def close(C, want, tol=2e-3):
+        bad = ((C.float() - want).abs() > tol * want.abs().max()).sum().item()
+        assert bad == 0, f"{bad} elements off"
+        assert _rel(C, want) < 1e-5
+
+    def run(problems):
+        used, shared = ops.gemm_grouped_plan(ops.GEMM_TN, ops.EPI_F32, problems)
+        assert used
+        for (_, _, G, kw), sh in zip(problems, shared):
+            if kw.get("accumulate"):
+                continue
+            G.zero_() if sh else G.fill_(float("nan"))
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, problems)
+        return shared
+
+    dY, X = _rand((R, P), dev, 1, 0.1), _rand((R, Q), dev, 2, 0.1)
+    want = dY.float().t() @ X.float()
+    C = torch.empty(P, Q, dtype=F32, device=dev)
+    ops.gemm_route_counts(reset=True)
+    shared = run([(dY, X, C, dict(splits=1, accumulate=False))])
+    close(C, want)
+    if not shared[0]:
+        first = C.clone()
+        for _ in range(10):
+            run([(dY, X, C, dict(splits=1, accumulate=False))])
+            assert torch.equal(C, first)
+    if R >= 256:
+        run([(dY, X, C, dict(splits=3, accumulate=False))])
+        close(C, want)
+        ops.gemm_grouped(ops.GEMM_TN, ops.EPI_F32, [(dY, X, C, dict(splits=2, accumulate=True))])
+        close(C, 2 * want)
+    bg = torch.full((P,), 0.5, dtype=F32, device=dev)
+    lo, hi = P // 3, 2 * P // 3
+    run([(dY, X, C, dict(splits=1, accumulate=False, colsum=bg, colsum_skip=(lo, hi)))])
+    close(C, want)
+    ref = dY.float().sum(0) + 0.5
+    ref[lo:hi] = 0.5
+    assert _rel(bg, ref) < 1e-5 and torch.all(bg[lo:hi] == 0.5)
+    shapes = [(P, Q, R), (384, 128, R), (768, 512, max(64, R - 72)), (1152, 128, R), (384, 256, max(8, R // 2))]
+    probs, wants = [], []
+    for i, (p_, q_, r_) in enumerate(shapes):
+        a, b = _rand((r_, p_), dev, 20 + i, 0.1), _rand((r_, q_), dev, 30 + i, 0.1)
+        probs.append((a, b, torch.empty(p_, q_, dtype=F32, device=dev), dict(splits=1, accumulate=False)))
+        wants.append(a.float().t() @ b.float())
+    run(probs)
+    for (_, _, G, _), w in zip(probs, wants):
+        close(G, w)
+    counts = ops.gemm_route_counts()
+    assert counts["r4"] >= 3 and counts["tile"] == 0 and counts["r3"] == 0
+
+
+@pytest.mark.parametrize("grid", ["16", "256"])
+@pytest.mark.parametrize("slices", [8, 3, 1])
+@pytest.mark.parametrize("whole", [True, False])
+def test_gemm_wgrad_sliced(dev, monkeypatch, whole, slices, grid):
+    """mofo_gemm_wgrad_sliced: a weight-gradient group with the reduction cut into row ranges (one per XCD label), partial sums in a
+    workspace, summed by a second kernel -- no atomics on the gradients.  whole: every output is whole 384 x 128 tiles (gemm_r4);
+    else ragged 256-row tiles (gemm_r3).  Problems with different reduction lengths (one whose last slice is short), fused
+    bias-gradient column sums with a skipped range, destinations AND workspace poisoned with NaN (every element must be written),
+    accumulate, bit-identical repeats; grid 16 makes every block walk several units of its slice."""
+    from mofo_amd import ops
+    monkeypatch.setenv("MOFO_GEMM_R3_GRID", grid)
+    shapes = ([(384, 128, 4100), (1152, 384, 2888), (384, 1536, 4100), (768, 256, 1090)] if whole
+              else [(520, 264, 4100), (384, 136, 2888), (256, 512, 4100), (264, 128, 1090)])
+    probs, wants, bgs = [], [], []
+    for i, (p_, q_, r_) in enumerate(shapes):
+        a, b = _rand((r_, p_), dev, 40 + i, 0.1), _rand((r_, q_), dev, 50 + i, 0.1)
+        bg = torch.full((p_,), 0.25, dtype=F32, device=dev)
+        kw = dict(accumulate=False, colsum=bg, colsum_skip=(p_ // 3, 2 * p_ // 3)) if i % 2 == 0 else dict(accumulate=False)
+        probs.append((a, b, torch.full((p_, q_), float("nan"), dtype=F32, device=dev), kw))
+        wants.append(a.float().t() @ b.float())
+        bgs.append((bg, a.float().sum(0), p_) if i % 2 == 0 else None)
+    n = ops.gemm_wgrad_sliced_ws(probs, slices)
+    assert n == slices * sum(p_ * q_ for p_, q_, _ in shapes)
+    ws = torch.full((n,), float("nan"), dtype=F32, device=dev)
+    ops.gemm_route_counts(reset=True)
+    ops.gemm_wgrad_sliced(probs, ws, slices)
+    for (_, _, G, _), w in zip(probs, wants):
+        assert ((G - w).abs() > 2e-3 * w.abs().max()).sum().item() == 0 and _rel(G, w) < 1e-5
+    for item in bgs:
+        if item is not None:
+            bg, cs, p_ = item
+            ref = cs + 0.25
+            ref[p_ // 3:2 * p_ // 3] = 0.25
+            assert _rel(bg, ref) < 1e-5
+    counts = ops.gemm_route_counts()
+    assert counts["r4" if whole else "r3"] == 1 and counts["tile"] == 0
+    first = [G.clone() for _, _, G, _ in probs]
+    for _ in range(5):
+        ops.gemm_wgrad_sliced(probs, ws, slices)
+        assert all(torch.equal(G, f) for (_, _, G, _), f in zip(probs, first))
+    acc = [(a, b, G, dict(accumulate=True)) for a, b, G, _ in probs]
+    ops.gemm_wgrad_sliced(acc, ws, slices)
+    for (_, _, G, _), w in zip(probs, wants):
+        assert _rel(G, 2 * w) < 1e-5
+    # a reduction shorter than the slices (most of them empty: they store zeros)
+    a, b = _rand((40, 384), dev, 1, 0.1), _rand((40, 128), dev, 2, 0.1)
+    G = torch.full((384, 128), float("nan"), dtype=F32, device=dev)
+    ops.gemm_wgrad_sliced([(a, b, G, dict(accumulate=False))], ws, slices)
+    assert _rel(G, a.float().t() @ b.float()) < 1e-5
+    with pytest.raises(RuntimeError):      # a workspace that is too small is refused
+        ops.gemm_wgrad_sliced(probs, ws[:n - 8], slices)
+
+
 @pytest.mark.parametrize("Bc,n_all,skip,N,K", [(3, 40, 16, 192, 128), (2, 1568, 160, 384, 384), (4, 300, 44, 768, 1536), (32, 160, 24, 128, 64)])
 def test_gemm_residual_row_map(dev, Bc, n_all, skip, N, K):
     """RESID_F32 / RESID_BF16 with a residual ROW MAP (rows_in > 0): the output is dense over the n_all - skip kept rows of each of
