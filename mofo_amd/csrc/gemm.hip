@@ -27,6 +27,7 @@
 #include "../../include/mofo_hip.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -1358,11 +1359,12 @@ static int r3_mode() {
     const char* e = getenv("MOFO_GEMM_R3");      // read per call: A/B switches inside one process
     return e ? atoi(e) : -1;
 }
-// tile rows of the ring kernel a weight-gradient group goes to: 384 (gemm_r4.h) under MOFO_GEMM_R4=1 when every output is whole
-// 384 x 128 tiles, else 256 (gemm_r3.h)
+// tile rows of the ring kernel a weight-gradient group goes to: 384 (gemm_r4.h) when every output is whole 384 x 128 tiles (ViT-B:
+// every width is a multiple of 384; same-process A/B, tools/wgrad_dec_ab.py, profiles/r06_wgrad_dec_ab.txt: encoder groups of 3 / 5 / 7
+// blocks 1.10 / 1.14 / 1.10 x gemm_r3), else 256 (gemm_r3.h: ViT-L's 1 024).  MOFO_GEMM_R4=0 keeps gemm_r3 everywhere.
 static int ring_tm(const mofo_gemm_args* a, int count) {
-    const char* e = getenv("MOFO_GEMM_R4");      // read per call: A/B switches inside one process
-    if (!e || atoi(e) != 1) return R3_TM;
+    const char* e = getenv("MOFO_GEMM_R4");      // read per call: A/B switches inside one process.  0: never gemm_r4; unset / 1: by shape
+    if (e && atoi(e) == 0) return R3_TM;
     for (int i = 0; i < count; ++i)
         if (a[i].M % R4_TM || a[i].N % R3_TN) return R3_TM;
     return R4_TM;
@@ -1427,8 +1429,6 @@ static int r3_launch(const mofo_gemm_args* a, int count, hipStream_t s) {
 }
 
 // ---- the 384 x 128 ring kernel (gemm_r4.h) and the SLICED weight-gradient launch.
-// MOFO_GEMM_R4 = 1: weight-gradient groups whose outputs are whole 384 x 128 tiles go to gemm_r4 instead of gemm_r3 (plain rounds /
-// tail chunks as r3_fill decides); unset / 0: gemm_r4 runs only behind mofo_gemm_wgrad_sliced.
 static bool r4_tiles(const mofo_gemm_args* a, int count) {
     for (int i = 0; i < count; ++i)
         if (a[i].M % R4_TM || a[i].N % R3_TN) return false;
@@ -1526,7 +1526,11 @@ extern "C" int mofo_gemm_wgrad_sliced(const mofo_gemm_args* a, int count, int sl
     }
     MOFO_CHECK_LAUNCH("mofo_gemm_wgrad_sliced(ring)");
     rp.count = count; rp.slices = slices; rp.accumulate = accumulate; rp.slab_stride = stride; rp.ws = ws;
-    hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(rp.start[count]), dim3(256), 0, s, rp);
+    switch (slices) {
+#define SLAB_REDUCE(S) case S: hipLaunchKernelGGL(wgrad_slab_reduce_kernel<S>, dim3(rp.start[count]), dim3(256), 0, s, rp); break
+        SLAB_REDUCE(1); SLAB_REDUCE(2); SLAB_REDUCE(3); SLAB_REDUCE(4); SLAB_REDUCE(5); SLAB_REDUCE(6); SLAB_REDUCE(7); SLAB_REDUCE(8);
+#undef SLAB_REDUCE
+    }
     MOFO_CHECK_LAUNCH("mofo_gemm_wgrad_sliced(reduce)");
     return MOFO_OK;
 }

@@ -13,8 +13,8 @@
 //   * the A fragments are SINGLE-buffered: the 4 MFMAs of row group i are the only readers of fa[i], so stage h + 1's fa[i] is read
 //     into the same registers right behind them; the B fragments (read by every row group) are double-buffered.  56 fragment
 //     VGPRs instead of 80 -- the kernel has to fit 256 (two waves per SIMD);
-//   * fragment addresses are per-lane constants (two sets: ring halves 0-64 KiB and 64-128 KiB, the stage and the second read of a
-//     fragment are 16-bit immediates): no address arithmetic in the MFMA stream (gemm_r3 spends two v_add3 per fragment pair).
+//   * fragment addresses are per-lane constants (ring laid out [image][buffer]: the buffer and the second read of a fragment are
+//     16-bit immediates): no address arithmetic in the MFMA stream (gemm_r3 spends two v_add3 per fragment pair).
 // Order inside step h (frags(h) in registers, stage h + 1 landed and visible, stages h + 2, h + 3 in flight, buffer h & 3 free):
 //     24 MFMAs of stage h in six row groups; behind group i: the reads of stage h + 1's fa[i] (group 0: its four B fragments too);
 //     behind groups 2..5: the wave's four LDS-DMA pieces of stage h + 4 into buffer h & 3 | lgkmcnt(0) | vmcnt(8) | barrier b_h.
@@ -24,18 +24,46 @@
 
 constexpr int R4_TM = 384, R4_KH = 32;
 constexpr int R4_IMG = R4_KH * 128 * 2;        // 8 KiB: one [32 k][128 cols] COL image
-constexpr int R4_STG = 4 * R4_IMG;             // 32 KiB: A0 | A1 | A2 | B
-constexpr int R4_NB = 4;
-constexpr int R4_RING = R4_NB * R4_STG;        // 128 KiB
+constexpr int R4_STG = 4 * R4_IMG;             // 32 KiB per stage: images A0, A1, A2, B
+#ifndef R4_NB
+#define R4_NB 4                                // ring buffers (4: 128 KiB, three stages in flight; 5: 160 KiB, four)
+#endif
+constexpr int R4_RING = R4_NB * R4_STG;
+constexpr int R4_ISTR = R4_NB * R4_IMG;        // the ring is laid out [image][buffer]: the buffers of ONE image are 8 KiB apart, so a
+                                               // fragment has ONE address register and the buffer is a 16-bit immediate (<= 4 x 8 KiB + 1 KiB)
 constexpr int R4_CH = 8;                       // stages per chunk of the tail split (256 reduction rows, like gemm_r3's)
 #ifndef R4_PRIO
 #define R4_PRIO 1
 #endif
-// placement of the four LDS-DMA pieces behind the row groups (build-time A/B: tools/gemm_r4_ab.py): 0 = groups 2, 3, 4, 5;
-// 1 = groups 0, 1, 2, 3 for waves 4-7 (the SIMD partners of waves 0-3 issue their pieces while the others multiply)
+// placement of the four LDS-DMA pieces behind the row groups: 0 = groups 2, 3, 4, 5; 1 = groups 0, 1, 2, 3 for waves 4-7 (the SIMD
+// partners of waves 0-3 issue their pieces while the others multiply): 0.95 x, profiles/r06_gemm_r4_ablate.txt
 #ifndef R4_DMA_SKEW
 #define R4_DMA_SKEW 0
 #endif
+// 1: fa[4] and fa[5] are double-buffered as well (their next-stage reads move to the head of the step), so the last fragment read of
+// a step is issued behind row group 3 and the lgkmcnt(0) in front of the barrier finds it done
+#ifndef R4_SPARE
+#define R4_SPARE 0
+#endif
+// timing-only ablation builds (wrong results; profiles/r06_gemm_r4_ablate.txt): drop the LDS-DMA pieces / the fragment reads / the MFMAs /
+// the per-step barrier from the main loop
+#ifndef R4_NO_DMA
+#define R4_NO_DMA 0
+#endif
+#ifndef R4_NO_READ
+#define R4_NO_READ 0
+#endif
+#ifndef R4_NO_MFMA
+#define R4_NO_MFMA 0
+#endif
+#ifndef R4_NO_BARRIER
+#define R4_NO_BARRIER 0
+#endif
+
+template <class F, int... Is>
+__device__ __forceinline__ void r4_static_for(F&& f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
 
 template <int EPI>
 __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
@@ -98,7 +126,7 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
     // fragment read addresses (LDS byte address of the FIRST ds_read_b64_tr_b16 of a fragment in ring buffer 0; the second read is
     // 4 k-rows = 1 024 B further, buffer b is b * 32 KiB further): read_frag<OPL_COL> of gemm.hip with ks = 0, resolved once
     const unsigned lds0 = (unsigned)(unsigned long long)LDS_PTR(smem);
-    unsigned aaddr[2][6], baddr[2][4];
+    unsigned aaddr[6], baddr[4];
     {
         const int g = lane >> 4, qq = (lane & 15) >> 2, pp = lane & 3;
         const int kr0 = 8 * g + qq;
@@ -107,15 +135,13 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int row = wm * 96 + 16 * i;
-            aaddr[0][i] = rowpart + (row >> 7) * R4_IMG + ((((row & 127) >> 4) ^ key) << 5);
-            aaddr[1][i] = aaddr[0][i] + 2 * R4_STG;
-            asm volatile("" : "+v"(aaddr[0][i]), "+v"(aaddr[1][i]));     // opaque: kept in registers, not re-derived per read
+            aaddr[i] = rowpart + (row >> 7) * R4_ISTR + ((((row & 127) >> 4) ^ key) << 5);
+            asm volatile("" : "+v"(aaddr[i]));     // opaque: kept in a register, not re-derived per read
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            baddr[0][j] = rowpart + 3 * R4_IMG + ((((wn * 64 + 16 * j) >> 4) ^ key) << 5);
-            baddr[1][j] = baddr[0][j] + 2 * R4_STG;
-            asm volatile("" : "+v"(baddr[0][j]), "+v"(baddr[1][j]));
+            baddr[j] = rowpart + 3 * R4_ISTR + ((((wn * 64 + 16 * j) >> 4) ^ key) << 5);
+            asm volatile("" : "+v"(baddr[j]));
         }
     }
     auto rd_frag = [&](unsigned base, int imm) -> bf16x8 {
@@ -152,7 +178,10 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
     // piece IDX (0-2: A sub-image IDX, 3: B) of stage t of segment c into ring buffer `buf`
     auto piece = [&](auto idx_tag, const Ctx& c, int t, int buf) {
         constexpr int IDX = decltype(idx_tag)::value;
-        unsigned char* dst = smem + buf * R4_STG + IDX * R4_IMG + wave * 1024;
+#if R4_NO_DMA
+        if (t >= R4_NB) return;
+#endif
+        unsigned char* dst = smem + IDX * R4_ISTR + buf * R4_IMG + wave * 1024;
         const unsigned kr = (unsigned)(c.k0 + t * R4_KH + 4 * wave);
         if constexpr (IDX < 3) lds_dma16<true>(c.ra, dst, c.va, (kr * (unsigned)c.lda + (unsigned)(c.m0 + 128 * IDX)) * 2u);
         else lds_dma16<true>(c.rb, dst, c.vb, (kr * (unsigned)c.ldb + (unsigned)c.n0) * 2u);
@@ -165,6 +194,9 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
     };
 
     bf16x8 fa[6], fb[2][4];
+#if R4_SPARE
+    bf16x8 fs[2][2];                            // fa[4], fa[5] by stage parity (fa[4], fa[5] themselves are unused then)
+#endif
     f32x4 acc[6][4], accb[6];
     constexpr bool CAN_COLSUM = true;
 
@@ -180,75 +212,110 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
             accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        // ---- prologue: stages 0-3 in flight; stages 0 and 1 landed; frags(0) in registers in EVERY wave (then buffer 0 is free)
-        stage_all(cur, 0, 0);
-        stage_all(cur, 1, 1);
-        stage_all(cur, 2, 2);
-        stage_all(cur, 3, 3);
-        G8_WAIT_VM(8);
+        // ---- prologue: stages 0 .. NB-1 in flight; stages 0 and 1 landed; frags(0) in registers in EVERY wave (then buffer 0 is free)
+#pragma unroll
+        for (int b = 0; b < R4_NB; ++b) stage_all(cur, b, b);
+        G8_WAIT_VM(4 * (R4_NB - 2));
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[0][j] = rd_frag(baddr[0][j], 0);
+        for (int j = 0; j < 4; ++j) fb[0][j] = rd_frag(baddr[j], 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) fa[i] = rd_frag(aaddr[0][i], 0);
+        for (int i = 0; i < 6; ++i) {
+#if R4_SPARE
+            if (i >= 4) fs[0][i - 4] = rd_frag(aaddr[i], 0);
+            else
+#endif
+                fa[i] = rd_frag(aaddr[i], 0);
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
 
-        // one step: multiplies stage h (ring buffer B) from registers, reads stage h + 1's fragments, issues stage h + 4 into buffer B
-        auto step = [&](auto b_tag, auto cs_tag, int h) {
-            constexpr int B = decltype(b_tag)::value;
+        // one step: multiplies stage h (ring buffer H % NB) from registers, reads stage h + 1's fragments, issues stage h + NB into
+        // the buffer of stage h
+        auto step = [&](auto h_tag, auto cs_tag, int h) {
+            constexpr int H = decltype(h_tag)::value;
             constexpr bool CS = decltype(cs_tag)::value;
-            constexpr int BN = (B + 1) & 3;                  // buffer of stage h + 1
-            constexpr int P = B & 1, PN = P ^ 1;             // B-fragment set multiplied / read
-            constexpr int HS = BN >> 1, IMM = (BN & 1) * R4_STG;
+            constexpr int B = H % R4_NB, BN = (H + 1) % R4_NB;     // buffers of stages h, h + 1
+            constexpr int P = H & 1, PN = P ^ 1;                    // double-buffered fragment set multiplied / read
+            constexpr int IMM = BN * R4_IMG;
 #if R4_PRIO
             __builtin_amdgcn_s_setprio(1);
 #endif
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
+#if R4_SPARE
+                const bf16x8 a_i = i >= 4 ? fs[P][i - 4] : fa[i];
+#else
+                const bf16x8 a_i = fa[i];
+#endif
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], fa[i], acc[i][j], 0, 0, 0);
-                if constexpr (CS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, fa[i], accb[i], 0, 0, 0);
+#if R4_NO_MFMA
+                for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[P][j]), "v"(a_i));
+#else
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fb[P][j], a_i, acc[i][j], 0, 0, 0);
+                if constexpr (CS) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a_i, accb[i], 0, 0, 0);
+#endif
                 __builtin_amdgcn_sched_barrier(0);
+#if !R4_NO_READ
                 if (i == 0) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) fb[PN][j] = rd_frag(baddr[HS][j], IMM);
+                    for (int j = 0; j < 4; ++j) fb[PN][j] = rd_frag(baddr[j], IMM);
                 }
-                fa[i] = rd_frag(aaddr[HS][i], IMM);
+#if R4_SPARE
+                if (i < 4) fa[i] = rd_frag(aaddr[i], IMM);
+                if (i == 1) fs[PN][0] = rd_frag(aaddr[4], IMM);
+                if (i == 2) fs[PN][1] = rd_frag(aaddr[5], IMM);
+#else
+                fa[i] = rd_frag(aaddr[i], IMM);
+#endif
+#else
+                if (i == 0) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[PN][j] = fb[P][j];
+#if R4_SPARE
+                    fs[PN][0] = fs[P][0];
+                    fs[PN][1] = fs[P][1];
+#endif
+                }
+#endif
 #if R4_DMA_SKEW
                 const int slot = wave >= 4 ? i : i - 2;
 #else
                 const int slot = i - 2;
 #endif
-                if (slot == 0) piece(std::integral_constant<int, 0>{}, cur, h + 4, B);
-                else if (slot == 1) piece(std::integral_constant<int, 1>{}, cur, h + 4, B);
-                else if (slot == 2) piece(std::integral_constant<int, 2>{}, cur, h + 4, B);
-                else if (slot == 3) piece(std::integral_constant<int, 3>{}, cur, h + 4, B);
+                if (slot == 0) piece(std::integral_constant<int, 0>{}, cur, h + R4_NB, B);
+                else if (slot == 1) piece(std::integral_constant<int, 1>{}, cur, h + R4_NB, B);
+                else if (slot == 2) piece(std::integral_constant<int, 2>{}, cur, h + R4_NB, B);
+                else if (slot == 3) piece(std::integral_constant<int, 3>{}, cur, h + R4_NB, B);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #if R4_PRIO
             __builtin_amdgcn_s_setprio(0);
 #endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // stage h + 1 is in registers: this wave is done with its buffer
-            G8_WAIT_VM(8);                                          // stage h + 2 landed (this wave's pieces); eight younger pieces keep flying
+            G8_WAIT_VM(4 * (R4_NB - 2));                            // stage h + 2 landed (this wave's pieces); the younger ones keep flying
             __builtin_amdgcn_sched_barrier(0);
+#if !R4_NO_BARRIER
             __builtin_amdgcn_s_barrier();                           // b_h
+#endif
             __builtin_amdgcn_sched_barrier(0);
+        };
+        // the buffer index has period NB, the fragment parity period 2: the loop body is PERIOD steps with both at compile time
+        constexpr int PERIOD = (R4_NB & 1) ? 2 * R4_NB : R4_NB;
+        auto body = [&](auto cs_tag, int h) {
+            r4_static_for([&](auto it) { step(it, cs_tag, h + decltype(it)::value); }, std::make_integer_sequence<int, PERIOD>{});
+        };
+        auto rest = [&](auto cs_tag, int h) {
+            r4_static_for([&](auto it) { if (h + decltype(it)::value < nk) step(it, cs_tag, h + decltype(it)::value); },
+                          std::make_integer_sequence<int, PERIOD - 1>{});
         };
         auto loops = [&](auto cs_tag) {
             int h = 0;
-            for (; h + 4 <= nk; h += 4) {
-                step(std::integral_constant<int, 0>{}, cs_tag, h);
-                step(std::integral_constant<int, 1>{}, cs_tag, h + 1);
-                step(std::integral_constant<int, 2>{}, cs_tag, h + 2);
-                step(std::integral_constant<int, 3>{}, cs_tag, h + 3);
-            }
-            if (h < nk) step(std::integral_constant<int, 0>{}, cs_tag, h);
-            if (h + 1 < nk) step(std::integral_constant<int, 1>{}, cs_tag, h + 1);
-            if (h + 2 < nk) step(std::integral_constant<int, 2>{}, cs_tag, h + 2);
+            for (; h + PERIOD <= nk; h += PERIOD) body(cs_tag, h);
+            rest(cs_tag, h);
         };
         if (do_colsum) loops(std::true_type{});
         else loops(std::false_type{});
@@ -296,6 +363,7 @@ struct SlabReduceP {
     long long slab_stride;
     const float* ws;
 };
+template <int S>
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(SlabReduceP P) {
     int gi = 0;
 #pragma nounroll
@@ -305,14 +373,12 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(SlabReduceP P) {
     const long long e = ((long long)((int)blockIdx.x - P.start[gi]) * 256 + threadIdx.x) * 4;
     if (e >= (long long)P.M[gi] * N) return;
     const float* src = P.ws + P.off[gi] + e;
-    f32x4 v[8];
+    f32x4 v[S];
 #pragma unroll
-    for (int s = 0; s < 8; ++s)
-        if (s < P.slices) v[s] = __builtin_nontemporal_load((const f32x4*)(src + (long long)s * P.slab_stride));
+    for (int s = 0; s < S; ++s) v[s] = __builtin_nontemporal_load((const f32x4*)(src + (long long)s * P.slab_stride));
     f32x4 sum = v[0];
 #pragma unroll
-    for (int s = 1; s < 8; ++s)
-        if (s < P.slices) sum += v[s];
+    for (int s = 1; s < S; ++s) sum += v[s];
     const int m = (int)(e / N), n = (int)(e - (long long)m * N);
     f32x4* dst = (f32x4*)(P.C[gi] + (long long)m * P.ldc[gi] + n);
     if (P.accumulate) sum += *dst;

@@ -297,11 +297,13 @@ def _pick_wgrad_blocks(D: int, hid: int, depth: int = 12, bucketed: bool = True)
         eff = g * t / (-(-g * t // 768) * 768)
         if eff > best_eff + 1e-9:
             best, best_eff = g, eff
-    if D % 256 == 0 and hid % 256 == 0 and os.environ.get("MOFO_GEMM_R3", "") != "0":
+    # tile rows of the ring kernel these widths go to (csrc/gemm.hip: ring_tm): 384 when every width is a multiple of 384 (ViT-B), else 256
+    tm = 384 if (D % 384 == 0 and hid % 384 == 0 and os.environ.get("MOFO_GEMM_R4", "") != "0") else 256
+    if D % tm == 0 and hid % tm == 0 and D % 128 == 0 and hid % 128 == 0 and os.environ.get("MOFO_GEMM_R3", "") != "0":
         # ring-kernel groups: clearly fuller rounds win (ViT-B: 7 blocks, 0.98 against 0.84); at equal, (nearly) whole rounds the ring
         # kernel wins on its main loop (ViT-L, 10 240 token rows: 2 blocks = 768 units = 3 rounds exactly, 1 005 against 946 TFLOP/s in
-        # the step, 49.66 -> 49.09 ms)
-        u = (3 * D // 256) * (D // 128) + (D // 256) * (D // 128) + (hid // 256) * (D // 128) + (D // 256) * (hid // 128)
+        # the step, 49.66 -> 49.09 ms).  ViT-B on 384-row tiles: 144 units per block, 7 blocks = 3.94 rounds, 5 (+ patch embed) = 2.9
+        u = (3 * D // tm) * (D // 128) + (D // tm) * (D // 128) + (hid // tm) * (D // 128) + (D // tm) * (hid // 128)
         ring_best, ring_eff = None, 0.0
         for g in range(2, min(3 if bucketed else 7, depth) + 1):
             eff = g * u / (-(-g * u // 256) * 256)
@@ -342,7 +344,13 @@ class PretrainRuntime:
         bucketed = _td.is_available() and _td.is_initialized() and _td.get_world_size() > 1
         self.wgrad_blocks = max(1, min(7, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
             _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio), dims.enc_depth, bucketed)
-        self.wgrad_blocks_dec = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
+        # DECODER (round 6): the weight gradients of ALL its blocks and of the head go into ONE launch at the end of its backward pass,
+        # the token reduction sliced over the 8 XCDs with partial sums in a workspace (ops.gemm_wgrad_sliced; no f32 atomics, no split-K
+        # passes over the gradients): 961 -> 816 us at ViT-B (tools/wgrad_dec_ab.py).  MOFO_WGRAD_SLICED=0: a grouped launch per
+        # MOFO_WGRAD_BLOCKS_DEC blocks with split reductions, as in rounds 1-5.
+        self.wgrad_sliced = os.environ.get("MOFO_WGRAD_SLICED", "1") == "1" and dec_prefix is not None and dims.dec_depth <= 7
+        self._slab_ws, self._slab_retired = None, []
+        self.wgrad_blocks_dec = max(1, dims.dec_depth) if self.wgrad_sliced else max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
         # experiment switch MOFO_ENC_BUCKETS="6,3,2,1": encoder blocks per gradient bucket, read ONCE here (plan_segments and
         # encoder_backward must agree on the bucket ends) and refused aloud when malformed
         self._bucket_override = None
@@ -530,6 +538,7 @@ class PretrainRuntime:
                 hid = int(d.dec_dim * d.mlp_ratio)
                 w.dec_c = NS(dx0=e(Mc, d.dec_dim), dxln=e(Mc, d.dec_dim), dh1=e(Mc, hid), dxbB=e(Mc, d.dec_dim), dao=e(Mc, d.dec_dim))
             w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self.wgrad_blocks_dec)
+            w.dec_s.sliced = self.wgrad_sliced
             # Shared work: in the FIRST decoder block the rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262)
             # -- a function of the position alone, and so are their LayerNorm 1 and qkv rows.  With the full model LayerNorm 1, the qkv
             # GEMM, its dgrad, the LayerNorm backward and the qkv weight-gradient reduction run on [B * n_vis visible rows | N position
@@ -668,9 +677,25 @@ class PretrainRuntime:
         Q = X.shape[1]
         ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=self._accumulate, colsum=bias_grad)
 
-    def _wgrad_group(self, problems):
+    def _wgrad_sliced(self, problems):
+        """a whole pass's weight gradients in one launch, the reduction sliced over the XCDs (ops.gemm_wgrad_sliced): partial sums in
+        ``self._slab_ws``, summed into the gradients by the call's second kernel -- every destination is plainly stored"""
+        probs = [(dY, X, G, dict(accumulate=self._accumulate, colsum=bg, colsum_skip=skip)) for dY, X, G, bg, skip in problems]
+        need = ops.gemm_wgrad_sliced_ws(probs, 8)
+        if self._slab_ws is None or self._slab_ws.numel() < need:
+            if self._slab_ws is not None:
+                self._slab_retired.append(self._slab_ws)     # a recorded launch list may hold its pointer: retired, never freed
+            self._slab_ws = torch.empty(need, dtype=F32, device=self.dev)
+        if not self._accumulate and os.environ.get("MOFO_ZERO_ALL", "0") != "1":
+            for pr in problems:
+                self.store.mark_overwritten(pr[2])
+        ops.gemm_wgrad_sliced(probs, self._slab_ws, 8)
+
+    def _wgrad_group(self, problems, sliced=False):
         """the weight gradients of one transformer block as ONE grouped launch: their 128x128 tiles together fill the
         chip (ViT-B encoder: 108+36+144+144), so no split-K -> plain stores instead of f32 atomics"""
+        if sliced and len(problems) <= 32:
+            return self._wgrad_sliced(problems)
         R = problems[0][0].shape[0]
         tiles = sum(((pr[0].shape[1] + 127) // 128) * ((pr[1].shape[1] + 127) // 128) for pr in problems)
         # A group that leaves the 256 CUs with fewer than ~2.3 tiles each is split along the token reduction until it has
@@ -777,15 +802,16 @@ class PretrainRuntime:
         # and the one-tile-per-CU GEMMs (gemm_k2.h: 128 KiB of LDS) cannot start on a CU that still holds weight-gradient blocks.
         # MOFO_WGRAD_STREAM=side restores the side stream (main_enc / main_dec: per pass).
         mode = os.environ.get("MOFO_WGRAD_STREAM", "main")
+        sliced = self.wgrad_sliced and S is not None and getattr(S, "sliced", False)
         if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
-            self._wgrad_group(group)          # same stream: no fork / join events (each costs ~10 us of queue bubble)
+            self._wgrad_group(group, sliced)  # same stream: no fork / join events (each costs ~10 us of queue bubble)
             return
         side = self.side
         self._side_launched = True        # _backward joins the side stream once more at its end (see there)
         ops.host_op(lambda ev=S.ready[slot]: ev.record(torch.cuda.current_stream()))
         ops.use_stream(side)
         ops.host_op(lambda ev=S.ready[slot]: side.wait_event(ev))
-        self._wgrad_group(group)
+        self._wgrad_group(group, sliced)
         ops.host_op(lambda ev=S.done[slot]: ev.record(side))
         ops.use_stream(None)
         S.used[slot] = True

@@ -569,8 +569,10 @@ def test_vitb_b32_step_parity(dev):
     routes = ops.gemm_route_counts()
     # the B = 32 step really ran the forms the headline benchmark runs: persistent 128- and 256-row tiles, the one-tile-per-CU
     # split-K ring kernel (encoder fc2 / dfc1 / dqkv + patch embed: 12 + 12 + 12 + 1 launches), one-tile blocks (weight gradients)
-    # ... and (round 5) the 256 x 128 ring kernel: the encoder's weight gradients as groups of 7 + 5 blocks (+ the patch embed's)
-    assert routes["persistent"] > 0 and routes["persistent256"] > 0 and routes["k2"] == 37 and routes["tile"] > 0 and routes["r3"] == 2, routes
+    # ... and (round 6) the 384 x 128 ring kernel: the encoder's weight gradients as groups of 7 + 5 blocks (+ the patch embed's) and the
+    # decoder's four blocks + head as ONE sliced launch (mofo_gemm_wgrad_sliced); nothing is left on the 256 x 128 ring at ViT-B's widths
+    assert routes["persistent"] > 0 and routes["persistent256"] > 0 and routes["k2"] == 37 and routes["tile"] > 0, routes
+    assert routes["r4"] == 3 and routes["r3"] == 0, routes
     assert float(loss) == pytest.approx(ref_loss, rel=1e-3)
     assert float(loss) == pytest.approx(float(np.mean(pair_losses)), rel=5e-4)
     total = float(acc.double().norm())

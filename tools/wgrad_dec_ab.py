@@ -12,7 +12,9 @@ from mofo_amd import ops
 
 dev = torch.device("cuda:0")
 BF16, F32 = torch.bfloat16, torch.float32
-ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+QUICK = "--quick" in sys.argv          # two arms only (decoder sliced on gemm_r4, encoder 7 blocks on gemm_r4): build-variant screens (MOFO_HIP_LIB)
+_args = [a for a in sys.argv[1:] if not a.startswith("--")]
+ROUNDS = int(_args[0]) if _args else 3
 
 
 def rnd(g, *s):
@@ -98,6 +100,19 @@ flop = sum(2.0 * a.shape[0] * a.shape[1] * b.shape[1] for blk in allp for a, b, 
 ws = torch.empty(ops.gemm_wgrad_sliced_ws(probs_of(allp), 8), dtype=F32, device=dev)
 print(f"  decoder + head: {flop / 1e9:.1f} GFLOP, {sum(len(b) for b in allp)} problems, workspace {ws.numel() * 4 / 2**20:.0f} MiB")
 
+if QUICK:
+    tag = os.environ.get("MOFO_HIP_LIB", "in-tree build")
+    if "--only-enc" not in sys.argv:
+        compare(f"[{tag}] ViT-B decoder, 4 blocks + head", flop, [("sliced, ONE launch, 384 x 128 (gemm_r4), 8 slices + reduce", sliced({}, [probs_of(allp)], ws))])
+    del dec, head, allp, ws
+    if "--only-dec" in sys.argv:
+        sys.exit(0)
+    torch.cuda.empty_cache()
+    enc = [block(5120, 768, 3072, 100 + i) for i in range(7)]
+    compare(f"[{tag}] ViT-B encoder, 7 blocks in one launch", 2.0 * 5120 * 768 * 768 * 12 * 7,
+            [("ring 384 x 128 (gemm_r4), by shape", grouped({"MOFO_GEMM_R3": "1"}, [probs_of(enc)]))])
+    sys.exit(0)
+
 # correctness of the new route against today's (zeroed destinations for the atomics of today's route)
 setenv({"MOFO_GEMM_R3": "0"})
 for blk in allp:
@@ -137,7 +152,7 @@ torch.cuda.empty_cache()
 
 enc = [block(5120, 768, 3072, 100 + i) for i in range(7)]
 fl = 2.0 * 5120 * 768 * 768 * 12
-R3 = {"MOFO_GEMM_R3": "1"}
+R3 = {"MOFO_GEMM_R3": "1", "MOFO_GEMM_R4": "0"}
 R4 = {"MOFO_GEMM_R3": "1", "MOFO_GEMM_R4": "1"}
 for nb in (2, 3, 5, 7):
     compare(f"ViT-B encoder, {nb} block(s) in one launch: 5 120 token rows, D = 768", fl * nb,
