@@ -73,6 +73,61 @@ def cpu_baseline(seconds_budget: float):
             "sample": f"oracle fp32 torch-CPU train step, ViT-B dec4, batch 2, {n} timed steps after 1 warm-up ({dt:.1f} s)"}
 
 
+def calibration(dev):
+    """Three fixed probes timed in THIS process before the model's first step, so that the lines of two rounds (or two boxes of the
+    pool: they differ by up to 10 %) can be normalised: (a) the 256 x 256 counted-vmcnt GEMM at 8192^3 (matrix pipe + clocks under
+    load), (b) a pure streaming kernel over a 1 GiB f32 buffer (HBM), (c) the persistent 128 x 128 NT GEMM at the encoder's qkv
+    shape (5120 x 2304 x 768: L2 -> LDS fill path and launch ramp).  Each: >= 20 ms of the same kernel first, then 10 timed launches
+    between two events on the launch stream."""
+    from mofo_amd import ops
+    bf, f32 = torch.bfloat16, torch.float32
+
+    def timed(f, iters=10, warm_ms=20.0):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        f(); torch.cuda.synchronize()
+        e0.record(); f(); e1.record(); torch.cuda.synchronize()
+        one = max(e0.elapsed_time(e1), 1e-3)
+        for _ in range(int(warm_ms / one) + 1):
+            f()
+        e0.record()
+        for _ in range(iters):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+
+    g = torch.Generator(device=dev).manual_seed(4242)
+    out = {}
+    keep = {k: os.environ.get(k) for k in ("MOFO_GEMM8", "MOFO_GEMM_K2")}
+    try:
+        A = torch.randn(8192, 8192, device=dev, generator=g).mul_(0.1).to(bf)
+        Bm = torch.randn(8192, 8192, device=dev, generator=g).mul_(0.1).to(bf)
+        Cm = torch.empty(8192, 8192, dtype=bf, device=dev)
+        os.environ["MOFO_GEMM8"] = "1"
+        t = timed(lambda: ops.gemm(ops.GEMM_NT, ops.EPI_BF16, A, Bm, Cm))
+        out["gemm8_8192_tflops"] = round(2.0 * 8192 ** 3 / t / 1e12, 1)
+        del A, Bm, Cm
+        os.environ["MOFO_GEMM8"] = "0"
+        os.environ["MOFO_GEMM_K2"] = "0"
+        X = torch.randn(5120, 768, device=dev, generator=g).mul_(0.1).to(bf)
+        W = torch.randn(2304, 768, device=dev, generator=g).mul_(0.1).to(bf)
+        Y = torch.empty(5120, 2304, dtype=bf, device=dev)
+        t = timed(lambda: ops.gemm(ops.GEMM_NT, ops.EPI_BF16, X, W, Y))
+        out["gemm128_enc_qkv_tflops"] = round(2.0 * 5120 * 2304 * 768 / t / 1e12, 1)
+        del X, W, Y
+        src = torch.empty(1 << 28, dtype=f32, device=dev).normal_(generator=g)
+        dst = torch.empty(1 << 28, dtype=bf, device=dev)
+        t = timed(lambda: ops.cast_bf16(src, dst), iters=10)
+        out["stream_1gib_gbps"] = round(6.0 * (1 << 28) / t / 1e9, 1)
+        del src, dst
+    finally:
+        for k, v in keep.items():
+            os.environ.pop(k, None)
+            if v is not None:
+                os.environ[k] = v
+        torch.cuda.empty_cache()
+    return out
+
+
 def self_launch(n: int) -> int:
     """run `python -m torch.distributed.run --nproc-per-node n bench.py <same arguments>` as a child process and relay its output"""
     import socket
@@ -113,6 +168,7 @@ def main():
                          "normalised inside the gather / target kernels (side measurement)")
     ap.add_argument("--fp8", action="store_true", help="side measurement (BASELINE configs[4]): the four forward Linears of every block (qkv, proj, fc1, "
                                                        "fc2) on OCP e4m3 operands with the block-scaled MFMA; attention and the backward bf16")
+    ap.add_argument("--no-calibration", action="store_true", help="skip the three fixed probes of config.calibration (~1 s)")
     ap.add_argument("--model", choices=["vitb16", "vitl32"], default="vitb16",
                     help="vitb16: the headline workload (BASELINE configs[1]/[2]); vitl32: ViT-L, 32 frames (configs[4] in bf16; side measurement)")
     args = ap.parse_args()
@@ -184,6 +240,14 @@ def main():
     from mofo_amd.dist import DataParallel
     from mofo_amd.masking_generator import TubeMaskingGenerator, TubeMaskingGenerator_BB
 
+    calib = None
+    if not args.no_calibration:
+        try:
+            calib = calibration(dev)
+        except Exception as exc:      # a probe must never take the measurement down with it
+            calib = {"error": f"{type(exc).__name__}: {exc}"}
+        if rank == 0:
+            print(f"[bench] calibration: {calib}", file=sys.stderr, flush=True)
     torch.manual_seed(0)           # identical random-init replica on every rank (DDP would broadcast rank 0's)
     if args.model == "vitl32":     # BASELINE configs[4] shapes (--fp8: its e4m3 forward Linears): 3136 tokens, 320 visible
         model = mp.pretrain_videomae_large_patch16_224(decoder_depth=4, num_frames=32).to(dev)
@@ -319,6 +383,40 @@ def main():
             if rank == 0:
                 print("[bench] data-parallel route A/B (ms per step, 5 steps each, max over ranks): " +
                       "; ".join(f"{k}: {v}" for k, v in ms.items()) + f" -> {best}", file=sys.stderr, flush=True)
+    # Route A/B at N = 1 (round-5 review, item 2): the routes this round added -- the decoder's weight gradients as ONE sliced launch,
+    # 384-row ring tiles -- against the round-5 routes (a grouped launch per decoder block with split reductions, 256-row ring tiles),
+    # 5 untimed steps each in THIS process on THIS box; the faster one is kept for the timed region, both are reported.
+    route_ab = None
+    if world == 1 and not force_dp and os.environ.get("MOFO_ROUTE_AB", "1") == "1" and args.model == "vitb16":
+        keys = ("MOFO_WGRAD_SLICED", "MOFO_GEMM_R4")
+        if all(os.environ.get(k) is None for k in keys):
+            combos = [("round-6 routes (sliced decoder weight gradients, 384 x 128 ring)", {}),
+                      ("round-5 routes (MOFO_WGRAD_SLICED=0 MOFO_GEMM_R4=0)", {"MOFO_WGRAD_SLICED": "0", "MOFO_GEMM_R4": "0"})]
+            ms = {}
+
+            def _use1(env):
+                for k in keys:
+                    os.environ.pop(k, None)
+                os.environ.update(env)
+                model.runtime().invalidate_lists()
+
+            for rnd in range(2):                     # interleaved: A B A B
+                for name, env in combos:
+                    _use1(env)
+                    step(args.warmup - 1 if args.warmup else 0)
+                    torch.cuda.synchronize()
+                    ta = time.perf_counter()
+                    for _ in range(5):
+                        step(args.warmup - 1 if args.warmup else 0)
+                    torch.cuda.synchronize()
+                    ms.setdefault(name, []).append((time.perf_counter() - ta) / 5 * 1e3)
+            ms = {k: round(min(v), 3) for k, v in ms.items()}
+            best = min(ms, key=ms.get)
+            _use1(dict(combos)[best])
+            step(args.warmup - 1 if args.warmup else 0)
+            route_ab = {"ms_per_step": ms, "chosen": best}
+            print("[bench] route A/B (ms per step, best of 2 x 5 steps): " + "; ".join(f"{k}: {v}" for k, v in ms.items()) + f" -> {best}",
+                  file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -371,7 +469,7 @@ def main():
                       "exposed_allreduce_ms_per_rank": exposed_per_rank,
                       "allreduce_value_check": None if ar_check is None else ("ok" if ar_check["ok"] else ("error: " + ar_check["error"] if "error" in ar_check else "fail")),
                       "allreduce_value_check_max_rel": None if ar_check is None or ar_check["max_rel"] != ar_check["max_rel"] else float("%.3e" % ar_check["max_rel"]),
-                      "dp_route_ab": dp_ab, "grad_transport": ("bf16" if os.environ.get("MOFO_GRAD_BF16") == "1" else "f32") if (world > 1 or force_dp) else None,
+                      "dp_route_ab": dp_ab, "route_ab": route_ab, "calibration": calib, "grad_transport": ("bf16" if os.environ.get("MOFO_GRAD_BF16") == "1" else "f32") if (world > 1 or force_dp) else None,
                       "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 2),
                       "gpu_phase_s": round(gpu_phase_s, 2), "timed_s": round(dt, 3)}}
 
@@ -418,6 +516,14 @@ def main():
                     out["roofline"]["traffic_source"] = "recorded: %s (csrc sha256 %s)" % (tname, csrc_sha()[:12])
             except Exception:
                 pass
+        # the five largest kernel classes of the instrumented warm-up steps (ms per step, rate as a fraction of the class's roofline):
+        # `roofline` above follows whichever class is the largest on THIS box, this list lets two lines be compared class by class
+        top = sorted(warm.items(), key=lambda kv: -kv[1]["ms"])[:5]
+        out["config"]["kernel_classes"] = [
+            {"class": names.get(k, "_".join(str(x) for x in k)), "launches_per_step": v["launches"] // max(1, n_instr),
+             "ms_per_step": round(v["ms"] / max(1, n_instr), 3),
+             "frac": round(v["work"] / (v["ms"] * 1e-3) / (PEAK_BF16 if k in mfma_keys or k[0] in ("gemm", "attn_fwd", "attn_bwd", "attn_bwd_dq", "attn_bwd_dkv") else PEAK_HBM), 4)}
+            for k, v in top]
         gem = [warm[k] for k in warm if k[0] == "gemm"]
         if gem:
             out["roofline"]["all_gemm_tflops"] = round(sum(g["work"] for g in gem) / sum(g["ms"] for g in gem) / 1e9, 2)

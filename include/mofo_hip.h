@@ -179,6 +179,7 @@ int mofo_attention_delta_range(const void* out, int ldo, const void* dout, int l
                                void* stream);
 int mofo_attention_bwd_dq_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                 int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
+/* (the dK/dV pass also CLEARS the dq columns of the rows 0 .. q_begin - 1 of every clip: no dQ pass writes them, the qkv dgrad reads them) */
 int mofo_attention_bwd_dkv_range(const void* qkv, int ldqkv, const void* dout, int lddo, const float* lse2, const float* delta,
                                  int B, int N, int H, float scale, int q_begin, void* dqkv, int lddqkv, void* stream);
 /* The dQ pass that also computes delta = rowsum(dO * O) of its query rows (out: laid out like dout) and WRITES it to delta_out for the

@@ -731,6 +731,15 @@ __global__ __launch_bounds__(NW * 64) void attn_dkv_kernel(const bf16_t* __restr
     bf16_t* drow = dqkv + ((size_t)b * N + ki) * lddqkv + h * HD;
     store_T(drow + D, dk0, dk1, FOLD >= 1 ? -scale : scale, hh);
     store_T(drow + 2 * D, dv0, dv1, 1.0f, hh);
+    if (ki < qb) {
+        // a key row that is not a query row (the last decoder block: the visible tokens): no dQ pass writes its dq columns, and the qkv
+        // dgrad / weight gradient read every row of dqkv -- cleared here, in store_T's own 8-byte pieces (was a torch fill kernel of
+        // 15-19 us per step in front of the dQ pass)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) *(u32x2*)(drow + 32 * dt + 8 * rg + 4 * hh) = u32x2{0u, 0u};
+    }
 }
 
 
@@ -1160,7 +1169,9 @@ extern "C" int mofo_attention_fwd_q8(const void* qkv, int ldqkv, int B, int N, i
     if (rc) return rc;
     if ((rc = check_range("mofo_attention_fwd_q8", N, q_begin))) return rc;
     if (!out || !lse2 || !out_e4m3 || !q_scale || !q_amax) MOFO_FAIL(MOFO_EINVAL, "mofo_attention_fwd_q8: null pointer");
-    if (ldo < H * 64 || ldo % 4 || ldo8 < H * 64 || ldo8 % 4) MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd_q8: bad ldo=%d / ldo8=%d", ldo, ldo8);
+    // the e4m3 rows leave in 8-byte stores (one per lane and 16 columns): row pitch and base must be 8-byte aligned
+    if (ldo < H * 64 || ldo % 4 || ldo8 < H * 64 || ldo8 % 8 || ((uintptr_t)out_e4m3 & 7))
+        MOFO_FAIL(MOFO_EUNSUPPORTED, "mofo_attention_fwd_q8: bad ldo=%d / ldo8=%d (ldo8 a multiple of 8, out_e4m3 8-byte aligned)", ldo, ldo8);
     hipStream_t s = (hipStream_t)stream;
     const float c = scale * 1.4426950408889634f;
     const void* dout = nullptr; int lddo = 0; void* dqkv = nullptr; int lddqkv = 0; float* delta = nullptr;

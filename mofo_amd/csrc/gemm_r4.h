@@ -40,11 +40,9 @@ constexpr int R4_CH = 8;                       // stages per chunk of the tail s
 #ifndef R4_DMA_SKEW
 #define R4_DMA_SKEW 0
 #endif
-// 1: fa[4] and fa[5] are double-buffered as well (their next-stage reads move to the head of the step), so the last fragment read of
-// a step is issued behind row group 3 and the lgkmcnt(0) in front of the barrier finds it done
-#ifndef R4_SPARE
-#define R4_SPARE 0
-#endif
+// TRIED AND NOT KEPT (profiles/r06_gemm_r4_ablate.txt): fa[4], fa[5] double-buffered too, so that the last fragment read of a step is issued
+// behind row group 3 and the lgkmcnt(0) in front of the barrier finds it done -- 0.97-1.00 x and 58 spilled registers; a fifth ring
+// buffer (160 KiB, four stages in flight) -- 1.00 x: the L2 -> LDS path delivers ~21-23 B/clk per CU whatever is in flight.
 // timing-only ablation builds (wrong results; profiles/r06_gemm_r4_ablate.txt): drop the LDS-DMA pieces / the fragment reads / the MFMAs /
 // the per-step barrier from the main loop
 #ifndef R4_NO_DMA
@@ -194,9 +192,6 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
     };
 
     bf16x8 fa[6], fb[2][4];
-#if R4_SPARE
-    bf16x8 fs[2][2];                            // fa[4], fa[5] by stage parity (fa[4], fa[5] themselves are unused then)
-#endif
     f32x4 acc[6][4], accb[6];
     constexpr bool CAN_COLSUM = true;
 
@@ -221,13 +216,7 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) fb[0][j] = rd_frag(baddr[j], 0);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-#if R4_SPARE
-            if (i >= 4) fs[0][i - 4] = rd_frag(aaddr[i], 0);
-            else
-#endif
-                fa[i] = rd_frag(aaddr[i], 0);
-        }
+        for (int i = 0; i < 6; ++i) fa[i] = rd_frag(aaddr[i], 0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -246,11 +235,7 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
 #endif
 #pragma unroll
             for (int i = 0; i < 6; ++i) {
-#if R4_SPARE
-                const bf16x8 a_i = i >= 4 ? fs[P][i - 4] : fa[i];
-#else
                 const bf16x8 a_i = fa[i];
-#endif
 #pragma unroll
 #if R4_NO_MFMA
                 for (int j = 0; j < 4; ++j) asm volatile("" ::"v"(fb[P][j]), "v"(a_i));
@@ -264,21 +249,11 @@ __global__ __launch_bounds__(512, 2) void gemm_r4_kernel(R3Group G, int total) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[PN][j] = rd_frag(baddr[j], IMM);
                 }
-#if R4_SPARE
-                if (i < 4) fa[i] = rd_frag(aaddr[i], IMM);
-                if (i == 1) fs[PN][0] = rd_frag(aaddr[4], IMM);
-                if (i == 2) fs[PN][1] = rd_frag(aaddr[5], IMM);
-#else
                 fa[i] = rd_frag(aaddr[i], IMM);
-#endif
 #else
                 if (i == 0) {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) fb[PN][j] = fb[P][j];
-#if R4_SPARE
-                    fs[PN][0] = fs[P][0];
-                    fs[PN][1] = fs[P][1];
-#endif
                 }
 #endif
 #if R4_DMA_SKEW

@@ -434,6 +434,8 @@ def attention_fwd(qkv, B, N, H, scale, out, lse2, q_begin=0, out8=None, q_scale=
         _chk(out8, F8, "out8", 2), _chk(q_scale, F32, "q_scale"), _chk(q_amax, F32, "q_amax")
         if out8.shape != out.shape or q_amax.numel() != FP8_AMAX_STRIPES or not q_amax.is_contiguous():
             raise ValueError("attention_fwd: out8 must have out's shape, q_amax the %d stripes of one site" % FP8_AMAX_STRIPES)
+        if _ld(out8) % 8 or out8.data_ptr() % 8:
+            raise ValueError("attention_fwd: out8 rows must be 8-byte aligned (row pitch a multiple of 8 bytes)")
         _run("mofo_attention_fwd_q8", ("attn_fwd",), 4.0 * B * H * (N - q_begin) * N * 64, _p(qkv), _ld(qkv), B, N, H, scale, q_begin, _p(out), _ld(out),
              _p(lse2), _p(out8), _ld(out8), _p(q_scale), _p(q_amax))
         return out

@@ -129,7 +129,10 @@ class FusedAdamW(torch.optim.Optimizer):
         # MOFO_FP8=1: this pass also writes the e4m3 shadow of the fp8 forward's weights (delayed per-matrix scale = 448 / the maximum the
         # PREVIOUS update left; ops.fp8_roll_scales).  Only while that shadow is current -- after a load_state_dict / a foreign write the
         # next forward re-quantises from the bf16 shadow with exact scales and this path resumes with the update after it.
-        q8 = hasattr(st, "shadow8") and st.shadow8_current()
+        # ... and only while nobody has written the masters since the bf16 shadow was made (the version counters, not just the epochs:
+        # a load_state_dict or manual write between the last forward and this step would otherwise be quantised with the OLD weights'
+        # delayed scale -- no margin, saturating at 448 -- and marked fresh, so the next forward would run on a mis-scaled shadow)
+        q8 = hasattr(st, "shadow8") and st.shadow8_current() and st._version() == st._shadow_version
         if q8:
             ops.fp8_roll_scales(st._amax_ws, st.w_scale, st.w_scale_inv, **gate)
         if ranges is not None:

@@ -57,6 +57,9 @@ _FLAGS = [
     ("synthetic_clips", 0, int, "length of the synthetic dataset (drifting sinusoid textures, deterministic per index)"),
     ("uint8_frames", False, "store_true", "dataset yields uint8 [H,W,T*3] frame stacks; normalisation runs on the GPU"),
     ("prefetch", True, "flag", "copy batch i+1 to the GPU on a side stream while step i runs (utils.DevicePrefetcher)"),
+    ("device_masks", False, "store_true", "draw the tube masks on the GPU (masking_generator.DeviceTubeMaskingGenerator: the reference generator's "
+                                          "distribution from a counter-based stream, no mask crosses PCIe) instead of taking the dataset's; the "
+                                          "stream's position is saved in / restored from the checkpoints"),
 ]
 
 
@@ -76,6 +79,22 @@ def get_args(argv=None):
         else:
             ap.add_argument(flag, default=default, type=kind, help=text)
     return ap.parse_args(argv)
+
+
+class DeviceMaskLoader:
+    """a loader whose batches carry masks drawn on the device: the last element of every tuple (the dataset's host mask) is replaced
+    by ``generator(batch_size)`` -- uint8 [B, N] on the GPU, 1 = masked -- which the engine takes as it is (no host round trip)"""
+
+    def __init__(self, loader, generator, device):
+        self.loader, self.generator, self.device = loader, generator, device
+        self.sampler = getattr(loader, "sampler", None)
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for batch in self.loader:
+            yield tuple(batch[:-1]) + (self.generator(batch[0].shape[0], device=self.device),)
 
 
 class SyntheticClips(torch.utils.data.Dataset):
@@ -175,6 +194,12 @@ class Pretrainer:
 
         if args.prefetch and self.device.type == "cuda":
             self.loader = utils.DevicePrefetcher(self.loader, self.device)
+        if getattr(args, "device_masks", False):
+            if self.with_boxes or self.device.type != "cuda":
+                raise SystemExit("--device_masks: tube masks on a GPU only (the motion-box generator reads per-clip boxes on the host)")
+            from .masking_generator import DeviceTubeMaskingGenerator
+            args.mask_generator = DeviceTubeMaskingGenerator(args.window_size, args.mask_ratio, seed=args.seed)   # utils.save_model / auto_load_model carry its state
+            self.loader = DeviceMaskLoader(self.loader, args.mask_generator, self.device)
         model.to(self.device)
         n_vis = args.window_size[0] * (args.window_size[1] * args.window_size[2] - int(args.mask_ratio * args.window_size[1] * args.window_size[2]))
         model.set_visible_tokens(n_vis)                                   # known on the host: no device sync on the first batch

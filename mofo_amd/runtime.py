@@ -315,6 +315,7 @@ def _pick_wgrad_blocks(D: int, hid: int, depth: int = 12, bucketed: bool = True)
 
 
 _GRAPHS = os.environ.get("MOFO_GRAPH", "0") == "1"
+_RING_SWITCHES = ("MOFO_GEMM_R3", "MOFO_GEMM_R3_TAIL", "MOFO_GEMM_R3_GRID", "MOFO_GEMM_R4")   # read per call by csrc/gemm.hip
 
 
 class PretrainRuntime:
@@ -341,16 +342,21 @@ class PretrainRuntime:
         # round exactly: 53.9 / 53.1 / 51.4 ms per step with 3 / 2 / 1 blocks per launch)
         # (in one process -- no process group at construction -- nothing is handed over at bucket ends and the groups may be larger)
         import torch.distributed as _td
-        bucketed = _td.is_available() and _td.is_initialized() and _td.get_world_size() > 1
+        # (MOFO_FORCE_DP=1: bench.py's one-rank rehearsal of the data-parallel path hands buckets over like a real N > 1 job, so its groups
+        # are the bucketed ones too -- otherwise the rehearsal would time group sizes no data-parallel job runs)
+        bucketed = (_td.is_available() and _td.is_initialized() and _td.get_world_size() > 1) or os.environ.get("MOFO_FORCE_DP") == "1"
         self.wgrad_blocks = max(1, min(7, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
             _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio), dims.enc_depth, bucketed)
         # DECODER (round 6): the weight gradients of ALL its blocks and of the head go into ONE launch at the end of its backward pass,
         # the token reduction sliced over the 8 XCDs with partial sums in a workspace (ops.gemm_wgrad_sliced; no f32 atomics, no split-K
         # passes over the gradients): 961 -> 816 us at ViT-B (tools/wgrad_dec_ab.py).  MOFO_WGRAD_SLICED=0: a grouped launch per
         # MOFO_WGRAD_BLOCKS_DEC blocks with split reductions, as in rounds 1-5.
-        self.wgrad_sliced = os.environ.get("MOFO_WGRAD_SLICED", "1") == "1" and dec_prefix is not None and dims.dec_depth <= 7
+        # The switch is read whenever a backward launch list is RECORDED (like MOFO_WGRAD_STREAM): bench.py times both routes in one process
+        # (config.route_ab); the scratch below is sized for the larger group either way.
+        self._sliced_capable = dec_prefix is not None and 1 <= dims.dec_depth <= 7
         self._slab_ws, self._slab_retired = None, []
-        self.wgrad_blocks_dec = max(1, dims.dec_depth) if self.wgrad_sliced else max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
+        self._blocks_dec_env = max(1, min(3, int(os.environ.get("MOFO_WGRAD_BLOCKS_DEC", "1"))))
+        self.wgrad_blocks_dec = self._blocks_dec_env
         # experiment switch MOFO_ENC_BUCKETS="6,3,2,1": encoder blocks per gradient bucket, read ONCE here (plan_segments and
         # encoder_backward must agree on the bucket ends) and refused aloud when malformed
         self._bucket_override = None
@@ -478,7 +484,7 @@ class PretrainRuntime:
                   ao=e(Mc, D), x_mid=e(Mc, D, dt=resid), xln2=e(Mc, D), mean2=e(Mc, dt=F32), rstd2=e(Mc, dt=F32), h1=e(Mc, hid), g=e(Mc, hid),
                   x_out=e(Mc, D, dt=resid))
 
-    def _scratch(self, M, D, H, B, n, group=1):
+    def _scratch(self, M, D, H, B, n, group=1, one_group=0):
         dev = self.dev
         hid = int(D * self.d.mlp_ratio)
         e = lambda *s, dt=BF16: torch.empty(*s, dtype=dt, device=dev)
@@ -488,8 +494,11 @@ class PretrainRuntime:
         # lives in 2 * group scratch sets / 2 * group + 1 ring buffers: one group being read by its launch, one being written.
         # The residual-stream GRADIENT lives in bf16 only (ring / dxbB): each LayerNorm backward reads it as bf16 and writes
         # one bf16 tensor -- no f32 copy is written and re-read (the forward residual stream stays f32).
-        return NS(group=group, ring=[e(M, D) for _ in range(2 * group + 1)], dxln=e(M, D),
-                  sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(2 * group)],
+        # ``one_group`` > 0 (decoder): a recording may also put all ``one_group`` blocks of the pass into ONE launch at its end (the sliced
+        # route); nothing of the next pass runs beside that launch, so one_group sets / one_group + 1 ring buffers hold it
+        nsets, nring = max(2 * group, one_group), max(2 * group + 1, one_group + 1)
+        return NS(group=group, ring=[e(M, D) for _ in range(nring)], dxln=e(M, D),
+                  sets=[NS(dh1=e(M, hid), dxbB=e(M, D), dqkv=e(M, 3 * D)) for _ in range(nsets)],
                   dao=e(M, D), delta=e(B * H * n, dt=F32), pending=[], gidx=0, gcount=0,
                   ready=[ev(), ev()], done=[ev(), ev()], used=[False, False], att_ready=ev(), att_done=ev())
 
@@ -537,8 +546,9 @@ class PretrainRuntime:
                 w.dec.append(self._block_ws_last(Md, Mc, d.dec_dim, d.dec_heads, B, N, self.dec_resid))
                 hid = int(d.dec_dim * d.mlp_ratio)
                 w.dec_c = NS(dx0=e(Mc, d.dec_dim), dxln=e(Mc, d.dec_dim), dh1=e(Mc, hid), dxbB=e(Mc, d.dec_dim), dao=e(Mc, d.dec_dim))
-            w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self.wgrad_blocks_dec)
-            w.dec_s.sliced = self.wgrad_sliced
+            w.dec_s = self._scratch(Md, d.dec_dim, d.dec_heads, B, N, group=self._blocks_dec_env,
+                                    one_group=d.dec_depth if self._sliced_capable else 0)
+            w.dec_s.is_dec = True
             # Shared work: in the FIRST decoder block the rows of the masked tokens are mask_token + pos[j] (modeling_pretrain.py:259-262)
             # -- a function of the position alone, and so are their LayerNorm 1 and qkv rows.  With the full model LayerNorm 1, the qkv
             # GEMM, its dgrad, the LayerNorm backward and the qkv weight-gradient reduction run on [B * n_vis visible rows | N position
@@ -658,8 +668,7 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dh1, W.fc1, C.dxln)
         self._ln_bwd(C.dxln, L.x_mid, W.ln2w, L.mean2, L.rstd2, C.dx0, None, C.dxbB, W.g_ln2w, W.g_ln2b)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, C.dxbB, W.proj, C.dao)
-        dq_dead = T.dqkv.view(B, n, 3 * D)[:, :qb, :D]
-        ops.host_op(lambda: dq_dead.zero_())
+        # (the dq rows of the skipped queries are cleared by the dK/dV pass below: mofo_attention_bwd_dkv_range)
         ops.attention_bwd_dq_delta(L.qkv, L.ao, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
         ops.attention_bwd_dkv(L.qkv, C.dao, L.lse, S.delta, B, n, H, scale, T.dqkv, q_begin=qb)
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dqkv, W.qkv, S.dxln)
@@ -676,6 +685,10 @@ class PretrainRuntime:
         R, P = dY.shape
         Q = X.shape[1]
         ops.gemm(ops.GEMM_TN, ops.EPI_F32, dY, X, G, splits=_wsplits(P, Q, R), accumulate=self._accumulate, colsum=bias_grad)
+
+    @property
+    def wgrad_sliced(self) -> bool:
+        return self._sliced_capable and os.environ.get("MOFO_WGRAD_SLICED", "1") == "1"
 
     def _wgrad_sliced(self, problems):
         """a whole pass's weight gradients in one launch, the reduction sliced over the XCDs (ops.gemm_wgrad_sliced): partial sums in
@@ -707,6 +720,16 @@ class PretrainRuntime:
         probs = [(dY, X, G, dict(splits=splits, accumulate=self._accumulate, colsum=bg, colsum_skip=skip)) for dY, X, G, bg, skip in problems]
         # which kernel takes the group, and which destinations receive f32 atomics from several workgroups (split reductions, or --
         # ring kernel -- the units of a last, partial round dealt in chunks): those must hold zeros, the others are plainly stored
+        # The C side reads the ring switches from the environment on EVERY call, the bookkeeping below is fixed when the list is
+        # recorded: a switch changed between recording and a replay would send atomics onto gradients zero_grad skipped (or the reverse).
+        # The recorded list therefore carries a check of the switches it was planned under; changing one needs invalidate_lists().
+        snap = tuple(os.environ.get(k) for k in _RING_SWITCHES)
+
+        def _same_switches(snap=snap):
+            if tuple(os.environ.get(k) for k in _RING_SWITCHES) != snap:
+                raise RuntimeError("a MOFO_GEMM_R3* / MOFO_GEMM_R4 switch changed after this backward was recorded: the recorded zero / overwrite "
+                                   "plan no longer matches the kernel's route -- call runtime.invalidate_lists() after changing it")
+        ops.host_op(_same_switches)
         ring, shared = ops.gemm_grouped_plan(ops.GEMM_TN, ops.EPI_F32, probs)
         if not ring and len(probs) > 13:
             # the 128 x 128 kernel takes 13 problems (three blocks + one) per launch
@@ -755,18 +778,17 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, T.dxbB, W.proj, S.dao)
         # the passes of mofo_attention_bwd as their own C-ABI calls (same stream, same kernels): each shows up under its own name in
         # the per-class timing.  (dQ and dK/dV on two streams measured neutral, round 1; retired in round 5.)
-        if True:
-            if n <= 160:
-                # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
-                ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
-            elif os.environ.get("MOFO_ATTN_DELTA_KERNEL", "0") == "1":
-                ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
-                ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-                ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-            else:
-                # the dQ pass computes delta = rowsum(dO * O) on the way and leaves it for the dK/dV pass (no delta kernel: 19 us per layer)
-                ops.attention_bwd_dq_delta(L.qkv, L.ao, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
-                ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+        if n <= 160:
+            # short sequences (the encoder's visible tokens): one fused kernel per (clip, head) behind the combined entry
+            ops.attention_bwd(L.qkv, L.ao, S.dao, L.lse, B, n, H, scale, T.dqkv, S.delta)
+        elif os.environ.get("MOFO_ATTN_DELTA_KERNEL", "0") == "1":
+            ops.attention_delta(L.ao, S.dao, B, n, H, S.delta)
+            ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+            ops.attention_bwd_dq(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+        else:
+            # the dQ pass computes delta = rowsum(dO * O) on the way and leaves it for the dK/dV pass (no delta kernel: 19 us per layer)
+            ops.attention_bwd_dq_delta(L.qkv, L.ao, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
+            ops.attention_bwd_dkv(L.qkv, S.dao, L.lse, S.delta, B, n, H, scale, T.dqkv)
         if share is not None:
             # the adjoint of the forward's row sharing: qkv gradient and residual gradient summed per cat row (visible rows copied,
             # position rows added over the clips that mask the position, f32), then dgrad / LayerNorm backward / weight gradient on
@@ -802,7 +824,7 @@ class PretrainRuntime:
         # and the one-tile-per-CU GEMMs (gemm_k2.h: 128 KiB of LDS) cannot start on a CU that still holds weight-gradient blocks.
         # MOFO_WGRAD_STREAM=side restores the side stream (main_enc / main_dec: per pass).
         mode = os.environ.get("MOFO_WGRAD_STREAM", "main")
-        sliced = self.wgrad_sliced and S is not None and getattr(S, "sliced", False)
+        sliced = self.wgrad_sliced and S is not None and getattr(S, "is_dec", False)
         if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
             self._wgrad_group(group, sliced)  # same stream: no fork / join events (each costs ~10 us of queue bubble)
             return
@@ -1068,6 +1090,8 @@ class PretrainRuntime:
         ops.gemm(ops.GEMM_NN, ops.EPI_BF16, dpred_bf16, s.bview(p + "head.weight"), w.d_decln)
         x_last = w.dec[-1].x_out if w.dec else x_full.view(w.Md, d.dec_dim)
         S.used, S.gidx, S.gcount = [False, False], 0, 0
+        # blocks per weight-gradient launch of THIS recording: all of them (one sliced launch at the end of the pass), or MOFO_WGRAD_BLOCKS_DEC
+        S.group = max(1, d.dec_depth) if self.wgrad_sliced else self._blocks_dec_env
         # the head's weight gradient (36 tiles) joins the first decoder block's grouped launch on the side stream
         S.pending.append((dpred_bf16, w.dec_ln, s.g2d(p + "head.weight"), s.gview(p + "head.bias"), (0, 0)))
         compact = bool(w.dec) and getattr(w.dec[-1], "compact", False)

@@ -265,11 +265,21 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
     if loss_scaler is None:
         raise NotImplementedError("deepspeed checkpoints belong to fine-tuning (out of scope)")
     path = os.path.join(args.output_dir, 'checkpoint-%s.pth' % str(epoch))
-    state = {'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
-             'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': args}
     # beyond the reference's five keys (its loaders ignore unknown ones): where the device-side mask generator stands, so that a
-    # resumed run continues the mask stream instead of replaying it from step 0 (args.mask_generator: masking_generator.DeviceTubeMaskingGenerator)
+    # resumed run continues the mask stream instead of replaying it from step 0 (args.mask_generator: masking_generator.DeviceTubeMaskingGenerator).
+    # The generator OBJECT never enters the file: 'args' is pickled, and an instance of a mofo_amd class inside it would make the
+    # checkpoint unreadable for the reference's loaders (any environment without this package) -- only its plain state dict travels.
     gen = getattr(args, "mask_generator", None)
+    saved_args = args
+    if gen is not None:
+        import copy
+        saved_args = copy.copy(args)
+        try:
+            delattr(saved_args, "mask_generator")
+        except AttributeError:
+            pass
+    state = {'model': {k: v.detach().cpu() for k, v in model_without_ddp.state_dict().items()},
+             'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': saved_args}
     if gen is not None and hasattr(gen, "state_dict"):
         state['mask_generator'] = gen.state_dict()
     save_on_master(state, path)

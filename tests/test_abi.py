@@ -91,3 +91,45 @@ def test_no_kernel_on_a_default_route_uses_scratch(tmp_path):
                 continue
             assert scratch == 0 and spill == 0, f"{src}: {name} uses {scratch} B of scratch, {spill} spilled VGPRs"
     assert seen > 150
+
+
+def test_lean_lds_dma_kernels_leave_m0_and_fresh_sgprs_alone(tmp_path):
+    """The ring kernels (gemm_r3.h, gemm_r4.h) issue their LDS-DMA pieces from inline asm in the LEAN form (gemm.hip: lds_dma16<true>):
+    M0 is overwritten without a save / restore and without a clobber (hipcc reserves m0: it cannot be named in a clobber list), and
+    no `s_nop 4` pads an SGPR operand that a VALU has just written.  Both are safe only while (a) nothing the COMPILER emits in those
+    kernels reads or writes M0 and (b) no v_readfirstlane / v_readlane result feeds a piece within the hazard's five wait states.
+    The hazard recognizer does not look inside asm statements, so this test reads the disassembly of the built code object."""
+    from mofo_amd import build
+    build.build()
+    llvm = "/opt/rocm/lib/llvm/bin"
+    if not os.path.exists(os.path.join(llvm, "clang-offload-bundler")):
+        pytest.skip("no clang-offload-bundler in this image")
+    import subprocess
+    obj = os.path.join(build.HERE, "build", "gemm.hip.o")
+    fat, co = str(tmp_path / "gemm.fatbin"), str(tmp_path / "gemm.co")
+    subprocess.check_call([os.path.join(llvm, "llvm-objcopy"), f"--dump-section=.hip_fatbin={fat}", obj])
+    subprocess.check_call([os.path.join(llvm, "clang-offload-bundler"), "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                           f"--input={fat}", f"--output={co}", "--unbundle"])
+    dis = subprocess.run([os.path.join(llvm, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True, check=True).stdout
+    checked = 0
+    for m in re.finditer(r"^[0-9a-f]+ <(\S*gemm_r[34]_kernel\S*)>:\n(.*?)(?=^[0-9a-f]+ <|\Z)", dis, flags=re.M | re.S):
+        name, body = m.group(1), m.group(2)
+        ins = [l.split("//")[0].strip() for l in body.splitlines() if l.strip() and not l.strip().startswith(("//", ";"))]
+        pieces = 0
+        for i, l in enumerate(ins):
+            if re.search(r"\bm0\b", l):
+                # the only M0 traffic: `s_mov_b32 m0, sN` of a piece, followed by s_nop 0 and the buffer_load ... lds that reads it
+                assert re.match(r"s_mov_b32 m0, s\d+$", l), f"{name}: compiler-generated M0 use: {l}"
+                assert ins[i + 1].startswith("s_nop") and re.match(r"buffer_load_dwordx4 v\d+, s\[\d+:\d+\], s\d+ offen lds$", ins[i + 2]), \
+                    f"{name}: M0 write not followed by its LDS-DMA: {ins[i:i + 3]}"
+                pieces += 1
+                # SGPR operands the VMEM instruction itself reads: descriptor quad and scalar offset -- none written by a VALU in the five
+                # instructions before it (the LDS base goes through `s_mov_b32 m0`, a SALU read: the hardware interlocks that one)
+                q0, q1, soff = re.match(r"buffer_load_dwordx4 v\d+, s\[(\d+):(\d+)\], (s\d+)", ins[i + 2]).groups()
+                regs = {soff} | {f"s{k}" for k in range(int(q0), int(q1) + 1)}
+                for prev in ins[max(0, i - 3):i + 2]:
+                    w = re.match(r"v_read(?:first)?lane_b32 (s\d+),", prev)
+                    assert not (w and w.group(1) in regs), f"{name}: {prev} feeds an LDS-DMA piece inside the VALU -> SGPR hazard window"
+        assert pieces >= 16, f"{name}: {pieces} LDS-DMA pieces found"
+        checked += 1
+    assert checked >= 2

@@ -462,6 +462,15 @@ def test_mask_generator_state_travels_with_the_checkpoint(tmp_path):
     utils.save_model(args, 4, model, model, opt, utils.NativeScalerWithGradNormCount())
     ck = torch.load(str(tmp_path / "checkpoint-4.pth"), map_location="cpu", weights_only=False)
     assert ck["mask_generator"] == {"seed": 11, "clips_drawn": 640, "world_size": 2}
+    assert not hasattr(ck["args"], "mask_generator") and args.mask_generator is gen      # the object stays out of the file, the caller keeps it
+    # the file unpickles where this package does not exist (the reference's loaders: any interpreter without mofo_amd on its path)
+    import subprocess
+    import sys
+    code = ("import sys, torch; sys.modules['mofo_amd'] = None; ck = torch.load(sys.argv[1], map_location='cpu', weights_only=False); "
+            "print(sorted(ck)); assert 'mofo_amd' not in repr(type(ck['args']))")
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path / "checkpoint-4.pth")], capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "'args', 'epoch', 'mask_generator', 'model', 'optimizer', 'scaler'" in r.stdout
     gen2 = DeviceTubeMaskingGenerator((8, 14, 14), 0.9, seed=0, rank=1, world_size=2)
     args2 = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="", mask_generator=gen2)
     utils.auto_load_model(args2, model, model, opt, utils.NativeScalerWithGradNormCount())

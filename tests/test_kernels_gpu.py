@@ -1109,7 +1109,7 @@ def test_attention_query_range(dev, B, N, H, qb):
     """The *_range entries (queries q_begin .. N - 1 of every clip only, out / dout compact): what the last decoder block runs, whose
     visible-token outputs feed nothing.  Forward rows and dq rows are those of the whole-sequence call bit for bit (the same key
     loop per query, whatever tile the query lands in); dk / dv equal the whole-sequence backward with dO zeroed on the skipped
-    rows (dP = 0 and delta = 0 there, hence dS = 0); rows below q_begin of dq are left untouched; long (streaming), short (all
+    rows (dP = 0 and delta = 0 there, hence dS = 0); rows below q_begin of dq are CLEARED by the dK/dV pass; long (streaming), short (all
     tiles staged at once) and ragged sequences, aligned and unaligned q_begin."""
     from mofo_amd import ops
     D = H * 64
@@ -1143,7 +1143,7 @@ def test_attention_query_range(dev, B, N, H, qb):
     ops.attention_bwd_dkv(qkv, dout_c, lse2, delta2, B, N, H, scale, dq2, q_begin=qb)
     a, b = dq2.view(B, N, 3 * D), dqkv.view(B, N, 3 * D)
     assert torch.equal(a[:, qb:, :D], b[:, qb:, :D])                               # dq of the range
-    assert torch.all(a[:, :qb, :D] == 3.0)                                         # dq rows below q_begin untouched
+    assert torch.all(a[:, :qb, :D] == 0.0)                                         # dq rows below q_begin: cleared by the dK/dV pass (round 6)
     for name, sl in (("dk", slice(D, 2 * D)), ("dv", slice(2 * D, 3 * D))):
         # same products; with q_begin a multiple of 32 the query tiles coincide (only all-zero tiles are skipped: bit-identical),
         # otherwise the queries group differently inside the MFMA reduction (f32 summation order: last-bit differences in bf16)

@@ -1550,6 +1550,18 @@ def test_launcher_trains_checkpoints_and_resumes(dev, tmp_path, capsys):
     assert h8[0]["train_loss"] == pytest.approx(hf[0]["train_loss"], rel=1e-4)   # same pixels, same seed: same epoch
     hb = R.main(common[:-2] + ["--epochs", "1", "--mask_ratio_BB", "0.75"])
     assert np.isfinite(hb[0]["train_loss"])
+    # masks drawn on the device (--device_masks): two epochs with a checkpoint after each, then a resumed third epoch that continues the
+    # mask stream (the checkpoint carries the generator's position as a plain dict, never the object: utils.save_model)
+    out2 = str(tmp_path / "run_dm")
+    dm = common[:-2] + ["--output_dir", out2, "--device_masks", "--save_ckpt_freq", "1"]
+    hd = R.main(dm + ["--epochs", "2"])
+    assert all(np.isfinite(h["train_loss"]) for h in hd) and hd[1]["train_loss"] < hd[0]["train_loss"]
+    ck = torch.load(os.path.join(out2, "checkpoint-1.pth"), map_location="cpu", weights_only=False)
+    assert ck["mask_generator"]["clips_drawn"] == 2 * 16 and not hasattr(ck["args"], "mask_generator")
+    hd2 = R.main(dm + ["--epochs", "3"])
+    assert [h["epoch"] for h in hd2] == [2] and np.isfinite(hd2[0]["train_loss"])
+    ck = torch.load(os.path.join(out2, "checkpoint-2.pth"), map_location="cpu", weights_only=False)
+    assert ck["mask_generator"]["clips_drawn"] == 3 * 16
 
 
 def test_bench_json_contract(dev):
@@ -1574,6 +1586,12 @@ def test_bench_json_contract(dev):
     assert out["roofline"]["frac"] == pytest.approx(out["roofline"]["achieved"] / out["roofline"]["peak"], rel=1e-2)
     assert "workload" in out["config"] and "encoder_step" in out["config"]
     assert math.isfinite(out["config"]["final_loss"])
+    # round 6: three fixed probes (two lines can be normalised), the N = 1 route A/B, the five largest kernel classes
+    cal = out["config"]["calibration"]
+    assert set(cal) == {"gemm8_8192_tflops", "gemm128_enc_qkv_tflops", "stream_1gib_gbps"} and all(v > 0 for v in cal.values()), cal
+    ab = out["config"]["route_ab"]
+    assert len(ab["ms_per_step"]) == 2 and ab["chosen"] in ab["ms_per_step"]
+    assert len(out["config"]["kernel_classes"]) == 5 and all(0 < c["frac"] < 1 for c in out["config"]["kernel_classes"])
     # the same run with the recorded launch lists replayed as hipGraphs (MOFO_GRAPH=1, off by default: slower on this stack)
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "3", "--batch", "4", "--no-cpu-baseline",
                          "--no-kernel-events", "--no-encoder-step"], capture_output=True, text=True, timeout=600, env={**os.environ, "MOFO_GRAPH": "1"})
