@@ -347,6 +347,9 @@ class PretrainRuntime:
         bucketed = (_td.is_available() and _td.is_initialized() and _td.get_world_size() > 1) or os.environ.get("MOFO_FORCE_DP") == "1"
         self.wgrad_blocks = max(1, min(7, int(os.environ["MOFO_WGRAD_BLOCKS"]))) if os.environ.get("MOFO_WGRAD_BLOCKS") else \
             _pick_wgrad_blocks(dims.enc_dim, int(dims.enc_dim * dims.mlp_ratio), dims.enc_depth, bucketed)
+        # under data parallelism the encoder's bucket / group plan may be switched after construction (set_enc_plan: bench.py times the
+        # plans under the live exchange): the scratch is then sized for the largest group a plan may ask for
+        self._enc_group_cap = max(self.wgrad_blocks, min(7, dims.enc_depth) if bucketed else 1)
         # DECODER (round 6): the weight gradients of ALL its blocks and of the head go into ONE launch at the end of its backward pass,
         # the token reduction sliced over the 8 XCDs with partial sums in a workspace (ops.gemm_wgrad_sliced; no f32 atomics, no split-K
         # passes over the gradients): 961 -> 816 us at ViT-B (tools/wgrad_dec_ab.py).  MOFO_WGRAD_SLICED=0: a grouped launch per
@@ -528,7 +531,7 @@ class PretrainRuntime:
             w.enc_out = e(Me, d.enc_dim)
             w.enc_mean, w.enc_rstd = e(Me, dt=F32), e(Me, dt=F32)
             # encoder: three blocks' weight gradients per launch (432 tiles of 128 x 128 per block = 1.69 per CU; 1296 = 5.06)
-            w.enc_s = self._scratch(Me, d.enc_dim, d.enc_heads, B, n_vis, group=self.wgrad_blocks)
+            w.enc_s = self._scratch(Me, d.enc_dim, d.enc_heads, B, n_vis, group=self._enc_group_cap)
             w.d_encout = e(Me, d.enc_dim)
         if self.dec_prefix is not None:
             Md = B * N
@@ -845,6 +848,21 @@ class PretrainRuntime:
                 ops.host_op(lambda ev=S.done[k]: torch.cuda.current_stream().wait_event(ev))
                 S.used[k] = False
 
+    def set_enc_plan(self, buckets: Optional[List[int]], blocks: Optional[int] = None):
+        """switch the encoder's gradient buckets (blocks per all-reduce range, from the top block down; None: the default plan for the
+        group size) and the encoder blocks per grouped weight-gradient launch, after construction: the segments are planned again and
+        every recorded launch list is dropped.  For bench.py's A/B of {6, 3, 2, 1 buckets with 3-block groups} against {7, 5 buckets
+        with ring-kernel groups of 7 / 5} under the live exchange (round-5 review, item 6); every rank must make the same call."""
+        if blocks is not None:
+            if not 1 <= blocks <= self._enc_group_cap:
+                raise ValueError(f"set_enc_plan: {blocks} blocks per launch, this runtime's scratch holds groups of up to {self._enc_group_cap}")
+            self.wgrad_blocks = int(blocks)
+        if buckets is not None and (sum(buckets) != self.d.enc_depth or any(x <= 0 for x in buckets)):
+            raise ValueError(f"set_enc_plan: buckets {buckets} must be positive block counts that sum to the encoder depth {self.d.enc_depth}")
+        self._bucket_override = list(buckets) if buckets is not None else None
+        self.segments = self.plan_segments()
+        self.invalidate_lists()
+
     def enc_buckets(self) -> List[int]:
         """the encoder's gradient buckets of THIS runtime (the override of MOFO_ENC_BUCKETS, else by depth and group size; groups of
         more than three blocks exist in one process only, where no bucket is handed over: the plan then follows the three-block rule)"""
@@ -984,6 +1002,7 @@ class PretrainRuntime:
         d, s, p, S = self.d, self.store, self.enc_prefix, w.enc_s
         x_last = w.enc[-1].x_out if w.enc else w.enc_x0
         S.used, S.gidx, S.gcount = [False, False], 0, 0
+        S.group = self.wgrad_blocks          # (the scratch holds groups of up to _enc_group_cap blocks; set_enc_plan may have changed the size)
         self._ln_bwd(d_out_bf16, x_last, s.view(p + "norm.weight"), w.enc_mean, w.enc_rstd, None, None, S.ring[0],
                      s.gview(p + "norm.weight"), s.gview(p + "norm.bias"))
         seg = 1 if self.dec_prefix is not None else 0
@@ -1131,11 +1150,11 @@ class PretrainRuntime:
         return S.ring[j % len(S.ring)]       # gradient wrt the decoder input, bf16 [B*N, D]
 
     # ------------------------------------------------------------------ whole model
-    def _forward(self, w: NS):
+    def _forward(self, w: NS, frozen: bool = False):
         enc_out = self.encoder_forward(w)
         x_full = self.bridge_forward(w, enc_out)
         out = self.decoder_forward(w, x_full, w.n_msk)
-        if self.fp8:
+        if self.fp8 and not frozen:
             ops.fp8_update_scales(self.act_amax, self.act_scales)      # this forward's amax -> the next forward's scales
         return out
 
@@ -1145,7 +1164,9 @@ class PretrainRuntime:
             if not self._fp8_calibrated:       # delayed scaling needs one look at the activations before the first real step
                 self._fp8_calibrated = True
                 self._forward(w)
-        return self.cached(w, ("fwd", getattr(w, "src_u8", False)), lambda: self._forward(w))
+        # fp8_freeze (dist.GradSync.value_check): forwards that must quantise with the SAME delayed activation scales leave them alone
+        frozen = bool(self.fp8 and getattr(self, "fp8_freeze", False))
+        return self.cached(w, ("fwd", getattr(w, "src_u8", False), frozen), lambda: self._forward(w, frozen))
 
     def _loss_forward(self, w, normalize_target, grad_scale):
         d = self.d

@@ -259,6 +259,59 @@ def test_data_parallel_gradient_mean_two_ranks(tmp_path):
     assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:]))
 
 
+def _dp_plan_worker(rank, world, port, out):
+    """two gloo ranks switch the encoder's bucket / group plan after construction (runtime.set_enc_plan, what bench.py's data-parallel
+    A/B does): the new ranges tile the buffer, the exchange follows them, every rank ends with the same plan and the same mean"""
+    import torch.distributed as dist
+    from mofo_amd.dist import GradSync
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    model = _tiny_model()                                              # encoder depth 5
+    rt, st = _cpu_runtime(model)                                       # built inside a 2-rank group: bucketed, scratch cap for large groups
+    model.runtime = lambda: rt
+    sync = GradSync(model).install()
+    rec = {"cap": rt._enc_group_cap, "default": (rt.enc_buckets(), rt.wgrad_blocks, list(rt.segments))}
+    rt.set_enc_plan([3, 2], 3)
+    rec["switched"] = (rt.enc_buckets(), rt.wgrad_blocks, list(rt.segments))
+    g = torch.Generator().manual_seed(7 + rank)
+    local = torch.randn(st.total, generator=g)
+    st.grads.copy_(local / world)
+    for idx in range(len(rt.segments)):
+        rt._seg_now(idx)
+    rec["launched"] = list(sync.launched)
+    sync.finish()
+    rec["grads"], rec["local"] = st.grads.clone(), local
+    try:
+        rt.set_enc_plan([4, 2], 3)                                     # does not sum to the depth
+        rec["bad_plan"] = "accepted"
+    except ValueError as exc:
+        rec["bad_plan"] = str(exc)
+    rt.set_enc_plan(None, 2)
+    rec["back"] = (rt.enc_buckets(), rt.wgrad_blocks)
+    torch.save(rec, out + f".{rank}")
+    dist.destroy_process_group()
+
+
+def test_enc_plan_switch_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    out = str(tmp_path / "plan")
+    mp.spawn(_dp_plan_worker, args=(world, _free_port(), out), nprocs=world, join=True)
+    r = [torch.load(out + f".{i}") for i in range(world)]
+    assert r[0]["cap"] == 5 and r[0]["default"][:2] == r[1]["default"][:2]
+    for k in ("default", "switched", "back", "launched", "bad_plan"):
+        assert r[0][k] == r[1][k], k                                   # every rank: the same plan, the same ranges, in the same order
+    buckets, blocks, segs = r[0]["switched"]
+    assert buckets == [3, 2] and blocks == 3 and len(segs) == 3        # decoder + two encoder buckets
+    cover = sorted(segs)
+    assert cover[0][0] == 0 and all(a[1] == b[0] for a, b in zip(cover, cover[1:])) and cover[-1][1] == r[0]["grads"].numel()
+    assert [x[0] for x in r[0]["launched"]] == [0, 1, 2] and [(lo, hi) for _, lo, hi in r[0]["launched"]] == segs
+    mean = (r[0]["local"] + r[1]["local"]) / world
+    assert torch.allclose(r[0]["grads"], mean, rtol=1e-6, atol=1e-7) and torch.equal(r[0]["grads"], r[1]["grads"])
+    assert "sum to the encoder depth" in r[0]["bad_plan"] and r[0]["back"][1] == 2
+
+
 def _dp_check_worker(rank, world, port, out):
     """GradSync.value_check on two gloo ranks: the production order passes; a backward that finishes a range AFTER handing it to
     the all-reduce (what a too-early side-stream hand-off would amount to) is caught"""

@@ -531,6 +531,7 @@ def test_gemm_r3_ring_family(dev, monkeypatch, R, P, Q, grid, tail):
     plan does not flag as shared are poisoned with NaN first (every element must be stored), flagged ones are zeroed (atomics)."""
     from mofo_amd import ops
     monkeypatch.setenv("MOFO_GEMM_R3", "1")
+    monkeypatch.setenv("MOFO_GEMM_R4", "0")          # (outputs of whole 384 x 128 tiles would go to gemm_r4 by shape: test_gemm_r4_ring_family)
     monkeypatch.setenv("MOFO_GEMM_R3_GRID", grid)
     monkeypatch.setenv("MOFO_GEMM_R3_TAIL", tail)
 

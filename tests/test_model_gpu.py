@@ -410,6 +410,7 @@ def test_split_and_unsplit_workspaces_share_one_gradient_buffer(dev, monkeypatch
     xs = {b: O.keyed_clips(b, cfg).to(dev) for b in (1, 16)}       # decoder rows: 576 (never split) and 9 216 (two splits of >= 4 096)
     ms = {b: torch.from_numpy(np.stack([gen() for _ in range(b)])).bool().to(dev) for b in (1, 16)}
     seq = [1, 16, 1, 16, 16, 1] if order == "small_first" else [16, 1, 16, 1, 1, 16]
+    monkeypatch.setenv("MOFO_WGRAD_SLICED", "0")         # the round-1..5 decoder route (split reductions + f32 atomics): the sliced default never adds
     monkeypatch.setenv("MOFO_WGRAD_THR", "100000")       # every group may split ...
     monkeypatch.setenv("MOFO_WGRAD_TARGET", "2048")      # ... as far as its token rows allow (>= 4096 rows per split)
 
