@@ -44,6 +44,11 @@ constexpr int TILE = 32 * RS;        // one 32-row tile
 // 144-B rows were 2-way conflicted on the transposed reads: 23-26 % of the LDS cycles, and these kernels are LDS-bound).
 __device__ __forceinline__ int swz(int r) { return (((r >> 1) & 1) << 2) | ((r >> 2) & 3); }
 constexpr float NEG_BIG = -1.0e30f;
+// timing-only ablation build (wrong results; profiles/r06_attn_fwd_ablate.txt): the forward tile without its P V product -- the ceiling of
+// what an e4m3 P V (BASELINE configs[4]) could save
+#ifndef ATTN_ABL_NO_PV
+#define ATTN_ABL_NO_PV 0
+#endif
 
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 __device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
 
     f32x16 o0 = zero16(), o1 = zero16();
     float m = NEG_BIG, l = 0.f;
+    const float big = fast_exp2(thr);          // MODE 0: a tile's partial row sum beyond this sends the row to the exact path
 
     const int nkt = (N + 31) >> 5;
     u32x4 kreg = {0, 0, 0, 0}, vreg = {0, 0, 0, 0};
@@ -266,27 +272,34 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
         ATTN_STAMP(kt, 1);
         float p[16];
         if constexpr (MODE == 0) {
-            // running max m is kept in RAW score units; p = exp2(c * s - c * m) is one FMA + one v_exp per element
-            float mx = NEG_BIG;
+            // The reference maximum m of a row is kept in RAW score units; p = exp2(c * s - c * m) is one FMA + one v_exp per element.
+            // FAST path (round 6; profiles/r06_attn_fwd_ablate.txt: tracking the row maximum in every tile cost 11 % of this kernel): the
+            // tile is exponentiated against the reference the row ALREADY has and its maximum is not looked at.  Only a partial row sum
+            // beyond 2^thr -- some score more than ~thr - 4 log2 units above the reference; Inf / NaN included, which is how the first
+            // tile (m = -1e30) gets there -- sends the wave to the exact path, where the rows that tripped take the tile's maximum as
+            // their new reference (o, l rescaled) and the others keep theirs (alpha = 1, same p): what a row computes depends on that
+            // row's scores only, never on the rows it shares a wave with (mofo_attention_fwd_range: bit-identical rows in any tiling).
+            // p <= 2^thr, not <= 1: exponents are free in f32 / bf16, the sums stay far inside f32 (1 568 keys x 2^20).
             if constexpr (MASKED) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (kt * 32 + acc_row(r, hh) >= N) s[r] = NEG_BIG;
             }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-            // lazy rescale (guide T13): the reference max of a row moves only when the tile max exceeds it by more than thr
-            // (log2 units), so p <= 2^thr instead of <= 1 and the O-wide rescale pass runs in the first tile(s) only
-            const float mn = (mx - m) * c > thr ? mx : m;
-            const float nmc = -mn * c;
+            float nmc = -m * c;
             float ls = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 p[r] = fast_exp2(fmaf(s[r], c, nmc));
                 ls += p[r];
             }
-            if (__any(mn > m)) {   // wave-uniform: after the first tiles the running max rarely moves
+            const int own = !(ls <= big);
+            if (__any(own)) {   // wave-uniform (one v_cmp + s_cbranch on the common path): the first tile, then only where the scores really grow
+                const int trip = own | __shfl_xor(own, 32, 64);   // the two key halves of a query sit 32 lanes apart
+                float mx = NEG_BIG;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[r]);
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float mn = trip ? fmaxf(m, mx) : m;
                 const float alpha = fast_exp2((m - mn) * c);
                 l *= alpha;
 #pragma unroll
@@ -294,16 +307,28 @@ __global__ __launch_bounds__(NW * 64) void attn_q_kernel(const bf16_t* __restric
                     o0[r] *= alpha;
                     o1[r] *= alpha;
                 }
+                nmc = -mn * c;
+                ls = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    p[r] = fast_exp2(fmaf(s[r], c, nmc));
+                    ls += p[r];
+                }
+                m = mn;
             }
             l += ls;
-            m = mn;
             const bf16x8 pf0 = pack_frag(p, 0), pf1 = pack_frag(p, 1);
             ATTN_STAMP(kt, 2);
             ATTN_PRIO(1);
+#if ATTN_ABL_NO_PV
+            asm volatile("" ::"v"(pf0), "v"(pf1));
+            (void)Vt;
+#else
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 0, lane), pf0, o0, 0, 0, 0);
             o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 0, lane), pf1, o0, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 0, 1, lane), pf0, o1, 0, 0, 0);
             o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Vt, 1, 1, lane), pf1, o1, 0, 0, 0);
+#endif
             ATTN_PRIO(0);
         } else {
             f32x16 dp = ndl;
@@ -1101,14 +1126,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     }
 }
 
-// Forward softmax: a row's reference maximum moves only when a tile's maximum exceeds it by more than this many log2 units
-// (p <= 2^thr instead of <= 1; guide T13).  MOFO_ATTN_RESCALE_THR=0 restores the rescale-on-every-new-maximum form (tests
-// compare both); read per launch.
+// Forward softmax: a row's reference maximum moves only when a tile's partial row sum (16 of its 32 keys) exceeds 2^thr against the
+// reference it has (p <= 2^thr instead of <= 1; guide T13 taken one step further in round 6: the tile's maximum is not computed at
+// all on the common path).  MOFO_ATTN_RESCALE_THR=0 trips on every tile with a p above ~1 = the rescale-on-every-new-maximum form
+// (tests compare both); read per launch.
 // dK/dV pass: start delay (x 64 cycles) of the blocks in odd wave slots
 int attn_stagger() { return 10; }   // (any value from 5 to 30 gave the same -1.5 ... -3 %; 0 = off was the losing side: switch retired in round 5)
 float rescale_thr() {
     const char* e = getenv("MOFO_ATTN_RESCALE_THR");
-    return e ? (float)atof(e) : 6.0f;
+    return e ? (float)atof(e) : 20.0f;
 }
 
 int pick_nw(int N) {

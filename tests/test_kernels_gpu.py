@@ -1159,11 +1159,11 @@ def test_attention_query_range(dev, B, N, H, qb):
 
 
 def test_attention_fwd_lazy_rescale_branch(dev, monkeypatch):
-    """The forward kernel moves a row's reference maximum only when a tile's maximum exceeds it by more than
-    MOFO_ATTN_RESCALE_THR log2 units (default 6).  Random data never takes that branch after the first tile, so the input
-    FORCES it: chosen keys in late tiles (5, 23, 40 and the ragged last one) line up with chosen queries, scores jump by 20 to 60
-    log2 units there.  Checked against fp32 torch on the full tensors, and threshold 0 (rescale on every new maximum) against
-    the shipped threshold; rows below the threshold keep p <= 2^6 and must agree as well."""
+    """The forward kernel moves a row's reference maximum only when a tile's partial row sum exceeds 2^MOFO_ATTN_RESCALE_THR against
+    the reference the row has (default 20; the tile maximum is not computed on the common path).  Random data never takes that
+    branch after the first tile, so the input FORCES it: chosen keys in late tiles (5, 23, 40 and the ragged last one) line up with
+    chosen queries, scores jump by 20 to 60 log2 units there.  Checked against fp32 torch on the full tensors for thresholds 0
+    (rescale on every new maximum), 6 and the shipped 20; rows below the threshold keep p <= 2^thr and must agree as well."""
     from mofo_amd import ops
     B, N, H = 2, 1568 - 7, 2
     D = H * 64
@@ -1180,20 +1180,21 @@ def test_attention_fwd_lazy_rescale_branch(dev, monkeypatch):
     ref, s = _attn_ref(x, B, N, H, scale)
     lse_ref = (torch.logsumexp(s, -1) * 1.4426950408889634).detach()
     outs = {}
-    for thr in ("0", "6"):
+    for thr in ("0", "6", "20"):
         monkeypatch.setenv("MOFO_ATTN_RESCALE_THR", thr)
         out = torch.empty(B * N, D, dtype=BF16, device=dev)
         lse2 = torch.empty(B * H * N, dtype=F32, device=dev)
         ops.attention_fwd(qkv, B, N, H, scale, out, lse2)
         outs[thr] = (out.float(), lse2.view(B, H, N).clone())
-    for thr in ("0", "6"):
+    for thr in ("0", "6", "20"):
         out, lse2 = outs[thr]
         assert torch.isfinite(out).all() and torch.isfinite(lse2).all(), thr
         assert _rel(out, ref) < 8e-3, thr
         assert (out - ref.detach()).abs().max() < 0.06, thr          # every row, not just on average: a mis-scaled row is off by O(1)
         assert torch.allclose(lse2, lse_ref, atol=2e-2, rtol=1e-3), thr
-    assert (outs["0"][0] - outs["6"][0]).abs().max() < 0.04
-    assert torch.allclose(outs["0"][1], outs["6"][1], atol=1e-3, rtol=1e-5)
+    for thr in ("6", "20"):
+        assert (outs["0"][0] - outs[thr][0]).abs().max() < 0.04
+        assert torch.allclose(outs["0"][1], outs[thr][1], atol=1e-3, rtol=1e-5)
 
 
 def test_attention_bwd_split_entries(dev):

@@ -5,10 +5,11 @@
 # beside the launch count and average duration of the kernel-trace.  Writes gpurun_out/pmc_mfma/summary.txt; copy it to profiles/rNN_pmc_mfma_step.txt.
 # usage (GPU box): bash tools/pmc_mfma_step.sh [extra bench.py arguments, e.g. --model vitl32 --fp8]
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export MOFO_ROUTE_AB=0     # the step's default routes only (no in-process A/B of the round-5 routes)
 mkdir -p gpurun_out/pmc_mfma
 for pass in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE"; do
   n=$(echo $pass | cut -d' ' -f1)
-  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_mfma/$n -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-encoder-step --no-kernel-events "$@" > gpurun_out/pmc_mfma/$n.log 2>&1 || echo "pass $n failed"
+  rocprofv3 --pmc $pass --kernel-trace --output-format csv -d gpurun_out/pmc_mfma/$n -- python3 bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-encoder-step --no-kernel-events "$@" --no-calibration > gpurun_out/pmc_mfma/$n.log 2>&1 || echo "pass $n failed"
 done
 python3 - <<PY > gpurun_out/pmc_mfma/summary.txt
 import csv, glob, collections, re

@@ -3,12 +3,13 @@
 # switches, same box, back to back: per kernel name the launches per step, average duration and ms per step.
 # usage (GPU box): bash tools/trace_routes.sh NAME_A "ENV_A" NAME_B "ENV_B"   (ENV = "K=V K=V"; write "-" for none)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+export MOFO_ROUTE_AB=0
 STEPS=12; WARM=4
 run() {
   name=$1; envs=$2
   rm -rf gpurun_out/trace_$name; mkdir -p gpurun_out/trace_$name
   if [ "$envs" != "-" ]; then export $envs; fi
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_$name -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-encoder-step --no-kernel-events > gpurun_out/trace_$name/bench.json 2> gpurun_out/trace_$name/bench.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/trace_$name -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-encoder-step --no-kernel-events --no-calibration > gpurun_out/trace_$name/bench.json 2> gpurun_out/trace_$name/bench.err
   if [ "$envs" != "-" ]; then for kv in $envs; do unset ${kv%%=*}; done; fi
 }
 run "$1" "$2" && run "$3" "$4"
