@@ -23,12 +23,19 @@ class _Args:
     lr = 1.5e-4 * B / 256 * 8          # a learning rate at which 300 steps move the loss (the recipe's peak is reached after 40 epochs of warm-up)
 
 
-def run(resid):
+def run(resid, jitter=0.0):
+    """``jitter`` > 0: every initial weight is multiplied by (1 + jitter * N(0,1)) -- a perturbation BELOW the bf16 rounding of the GEMM
+    operands (2^-9): how far two runs that differ by rounding-level noise alone drift apart = the floor the bf16 stream is read against"""
     os.environ["MOFO_DEC_RESID"] = resid                 # read when the runtime is built
     from mofo_amd import modeling_pretrain as mp, optim_factory, utils
     from mofo_amd.masking_generator import TubeMaskingGenerator
     torch.manual_seed(0)
     model = mp.pretrain_videomae_base_patch16_224(decoder_depth=4).to(dev)
+    if jitter:
+        gj = torch.Generator(device=dev).manual_seed(99)
+        with torch.no_grad():
+            for p_ in model.parameters():
+                p_.mul_(1.0 + jitter * torch.randn(p_.shape, device=dev, generator=gj))
     init = {n: p.detach().clone() for n, p in model.named_parameters()}
     clips, mask_u8 = model.input_buffers(B, 160)
     g = torch.Generator(device=dev).manual_seed(11)
@@ -57,6 +64,7 @@ def run(resid):
 
 la, na, pa, p0 = run("bf16")
 lb, nb, pb, _ = run("f32")
+lc, nc, pc, p0c = run("f32", jitter=2.0 ** -11)
 print(f"# tools/drift_dec_resid.py: ViT-B, {B} clips per step, {NB} different synthetic batches in turn, {steps} AdamW steps (lr {_Args.lr:.2e}), same initial weights")
 print("# step   loss (decoder stream bf16)   loss (decoder stream f32)   relative difference")
 worst = 0.0
@@ -84,3 +92,9 @@ for kind, names in (("matrices (>= 2-D)", mat), ("vectors (biases, LayerNorm, ma
           f"|p_bf16 - p_f32| / |p_f32 - p_init| (share of the distance travelled): median {dt[len(dt) // 2]:.2e}, worst {dt[-1]:.2e}")
 wn = sorted(abs(na[n] - nb[n]) / nb[n] for n in mat)
 print(f"# norms of the {len(mat)} matrices: worst relative difference {wn[-1]:.2e}")
+# the floor: the f32-stream run against ITSELF started from weights jittered by 2^-11 relative (a quarter of a bf16 ulp)
+wl = max(abs(lc[it] - lb[it]) / abs(lb[it]) for it in range(steps))
+for kind, names in (("matrices (>= 2-D)", mat), ("vectors", vec)):
+    dt = sorted(float(((pc[n] - p0c[n]) - (pb[n] - p0[n])).double().norm() / (pb[n] - p0[n]).double().norm().clamp_min(1e-30)) for n in names)
+    print(f"# floor, {kind}: |update_f32' - update_f32| / |update_f32|: median {dt[len(dt) // 2]:.2e}, worst {dt[-1]:.2e}")
+print(f"# floor, loss: worst relative difference between the two f32-stream runs {wl:.2e}")
