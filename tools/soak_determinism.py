@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Race screen for the two-stream backward (GPU box only): the ViT-B B=32 forward + backward from identical state, many times; every
 repetition's loss and gradients against the first one's -- weight gradients (plain stores) bit for bit, the sums that are added with
-atomics (biases, LayerNorm, mask token, split-K decoder weights) to 1e-4 relative.  usage: soak_determinism.py [reps] [batch]"""
+atomics (biases, LayerNorm, mask token, the lone encoder_to_decoder gradient) to 1e-4 relative.  usage: soak_determinism.py [reps] [batch]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -40,10 +40,12 @@ for r in range(reps):
             continue
         rel = float((a - b).double().norm() / (a.double().norm() + 1e-30))
         worst_rel = max(worst_rel, rel)
-        if len(st.shape[n]) == 2 and not n.startswith("decoder.") and "encoder_to_decoder" not in n:
+        # round 6: the decoder's weight gradients are deterministic too (sliced launch: plain stores + a reduce, no atomics); only the lone
+        # encoder_to_decoder gradient (split reduction) and the 1-D sums (biases, LayerNorm, mask token) are added with f32 atomics
+        if len(st.shape[n]) >= 2 and "encoder_to_decoder" not in n and n != "mask_token":
             worst_bit += 1
             print("NOT bit-identical:", r, n, rel)
         assert rel < 1e-4, (r, n, rel)
 model.check_status()
-print(f"{reps} repetitions at B={B}: loss identical; encoder weight gradients bit-identical in all but {worst_bit} cases; worst relative "
+print(f"{reps} repetitions at B={B}: loss identical; encoder AND decoder weight gradients bit-identical in all but {worst_bit} cases; worst relative "
       f"difference of an atomically summed tensor {worst_rel:.2e}")
