@@ -994,6 +994,11 @@ def test_bench_two_ranks_rehearsal(dev):
     # the exchange checked itself (dist.GradSync.value_check) and every rank reported its exposed all-reduce time
     assert out["config"]["allreduce_value_check"] == "ok" and out["config"]["allreduce_value_check_max_rel"] < 1e-4
     assert len(out["config"]["exposed_allreduce_ms_per_rank"]) == 2
+    # round 6: routes AND the encoder's bucket plan were timed under the live exchange; both ranks chose the same arm (bench.py aborts
+    # otherwise), every arm reports its exposed all-reduce wait, and the plan that was kept is one of the two that were offered
+    ab = out["config"]["dp_route_ab"]
+    assert ab["plan_agreed"] is True and ab["chosen"] in ab["ms_per_step"] and set(ab["exposed_allreduce_ms"]) == set(ab["ms_per_step"])
+    assert len(ab["ms_per_step"]) == 8 and ab["enc_buckets"] in ([6, 3, 2, 1], [7, 5]) and ab["enc_group"] in (3, 7)
 
 
 def test_bench_self_launch_two_ranks(dev):
