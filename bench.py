@@ -346,9 +346,10 @@ def main():
     dp_ab = None
     if (world > 1 or force_dp) and os.environ.get("MOFO_DP_ROUTE_AB", "1") == "1":
         user = {k: os.environ.get(k) for k in ("MOFO_GEMM_K2", "MOFO_WGRAD_STREAM")}
-        routes = [("k2 on, weight gradients on the main stream", {}), ("k2 off, weight gradients on the main stream", {"MOFO_GEMM_K2": "0"}),
-                  ("k2 on, weight gradients on the side stream", {"MOFO_WGRAD_STREAM": "side"}),
-                  ("k2 off, weight gradients on the side stream", {"MOFO_GEMM_K2": "0", "MOFO_WGRAD_STREAM": "side"})]
+        # (default streams since round 6: the decoder's one sliced launch on the side stream, the encoder's groups on the main stream)
+        routes = [("k2 on, default streams", {}), ("k2 off, default streams", {"MOFO_GEMM_K2": "0"}),
+                  ("k2 on, all weight gradients on the side stream", {"MOFO_WGRAD_STREAM": "side"}),
+                  ("k2 off, all weight gradients on the side stream", {"MOFO_GEMM_K2": "0", "MOFO_WGRAD_STREAM": "side"})]
         if any(v is not None for v in user.values()):
             routes = [("the caller's routes", {k: v for k, v in user.items() if v is not None})]   # the caller fixed them: only the plans are timed
         # ... and the encoder's BUCKET PLAN (round-5 review, item 6): shrinking buckets 6, 3, 2, 1 with three-block weight-gradient groups
