@@ -12,6 +12,7 @@ fast path does not implement (dropout, drop-path, layer-scale, learnable pos-emb
 head_dim != 64) raise instead of silently computing something else.
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -24,6 +25,10 @@ __all__ = ["PretrainVisionTransformerEncoder", "PretrainVisionTransformerDecoder
 
 STATUS_BAD_MASK = 1      # a clip's visible-token count differs (the reference's reshape at :90 would raise)
 STATUS_BAD_UPSTREAM = 2  # fused loss was back-propagated with an upstream gradient != 1
+# The whole model's forward launches go out BEFORE the host-side bookkeeping of the step (the 218 version counters that tell whether
+# somebody wrote the fp32 masters, the autograd node): between the end-of-step synchronise and the first kernel the GPU idles, and that
+# bookkeeping was 40 of the 50 us the host needed to get there (tools/step_start_gap.py).  0 = check first, launch second.
+EARLY_LAUNCH = os.environ.get("MOFO_EARLY_LAUNCH", "1") != "0"
 
 
 def trunc_normal_(tensor, mean=0., std=1.):
@@ -175,13 +180,10 @@ class _DecoderFn(torch.autograd.Function):
 class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, mod, w, fused, normalize, grad_scale):
-        rt = mod._rt
-        rt.store.refresh_shadow()
-        rt.forward(w)
+        # the launches themselves were issued by PretrainVisionTransformer._launch before this node was built
         ctx.mod, ctx.w, ctx.fused = mod, w, fused
         _stamp(ctx, w)
         if fused:
-            rt.loss_forward(w, normalize, grad_scale)
             return w.loss.clone().reshape(())
         return w.pred.view(w.B, w.n_msk, -1).float()
 
@@ -476,12 +478,34 @@ class PretrainVisionTransformer(_FlatModule):
         ops.ingest_u8(w.frames_u8, clips)
         return clips
 
+    @staticmethod
+    def _launch(rt, w, fused, normalize, grad_scale):
+        """all launches of the forward (+ the fused target / loss).  The bf16 shadow of the weights is current unless somebody other than
+        the fused AdamW wrote the fp32 masters since the last optimizer step (load_state_dict, a manual init, a foreign optimizer);
+        finding that out means reading every parameter's version counter, so the launches go first and the check second -- a stale
+        shadow is refreshed and the forward (which only overwrites its outputs) is issued again.  The e4m3 forward keeps the strict
+        order: it updates its delayed activation scales as it goes."""
+        def go():
+            rt.forward(w)
+            if fused:
+                rt.loss_forward(w, normalize, grad_scale)
+        st = rt.store
+        if not EARLY_LAUNCH or rt.fp8 or st._shadow_version < 0:   # < 0: the shadow has never been written
+            st.refresh_shadow()
+            go()
+            return
+        go()
+        if st._version() != st._shadow_version:
+            st.refresh_shadow()
+            go()
+
     # -- reference API -------------------------------------------------------------------------------------------
     def forward(self, x, mask):
         """[B,3,T,H,W] f32, mask bool [B,N] (True = masked) -> [B, N_mask, 1536] f32 predictions, autograd-connected.
         ``x`` may also be the loader's uint8 frame stack [B,H,W,T*3] (transforms.py:346-360): ToTorchFormatTensor +
         GroupNormalize are then applied inside the kernels that read the pixels, with bit-identical results."""
         rt, w = self._prepare(x, mask)
+        self._launch(rt, w, False, True, 1.0)
         return _ModelFn.apply(self._anchor, self, w, False, True, 1.0)
 
     # -- fused fast path -----------------------------------------------------------------------------------------
@@ -490,6 +514,7 @@ class PretrainVisionTransformer(_FlatModule):
         loss; ``loss.backward()`` runs the hand-written backward.  ``grad_scale`` pre-multiplies d(loss) (1/world_size
         turns the data-parallel SUM all-reduce into DDP's mean)."""
         rt, w = self._prepare(x, mask)
+        self._launch(rt, w, True, bool(normlize_target), float(grad_scale))
         return _ModelFn.apply(self._anchor, self, w, True, bool(normlize_target), float(grad_scale))
 
 

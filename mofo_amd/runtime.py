@@ -601,7 +601,9 @@ class PretrainRuntime:
         if mask is not None:
             if mask.data_ptr() != w.mask_u8.data_ptr():       # a loader may write masks straight into the persistent buffer, like clips
                 w.mask_u8.copy_(mask.reshape(w.B, -1), non_blocking=True)
-            ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status)
+            # persistent buffers on both sides: replayed from a one-entry list like every other launch of the step (the checked call was
+            # 15 us of host time in front of the first kernel of the step, tools/step_start_gap.py)
+            self.cached(w, ("mask_idx",), lambda: ops.mask_to_indices(w.mask_u8, w.n_vis, w.vis_idx, w.msk_idx, w.status))
 
     # ------------------------------------------------------------------ transformer block
     def _block_fwd(self, W, L, x_in, B, n, H, share=None, qb=0):

@@ -126,6 +126,41 @@ def test_tiny_fused_training_steps(dev, mode):
         assert float(sd[n].double().norm()) == pytest.approx(g["param_stats_after3"][i, 0], rel=1e-3, abs=1e-6), n
 
 
+def test_early_launch_sees_foreign_weight_writes(dev, monkeypatch):
+    """modeling_pretrain._launch issues the forward BEFORE it reads the parameters' version counters; a write to the fp32 masters by
+    somebody other than the fused AdamW (here: load_state_dict and an in-place scale between two steps) must still reach the bf16
+    shadow the kernels read -- the step is issued again.  Bit-identical to the strict order (check first, launch second)."""
+    from mofo_amd import modeling_pretrain as mp, optim_factory, utils
+    from oracle import pretrain_oracle as O
+    cfg = O.TINY
+    x = O.keyed_clips(2, cfg).to(dev)
+    mask = torch.from_numpy(np.load(os.path.join(G, "masks.npz"))["tube_tiny_s10"]).bool().to(dev)
+    runs = {}
+    for early in (True, False):
+        monkeypatch.setattr(mp, "EARLY_LAUNCH", early)
+        model, P = _build(cfg, "xavier", dev)
+        opt = optim_factory.create_optimizer(_Args, model)
+        scaler = utils.NativeScalerWithGradNormCount()
+        losses = []
+        for s in range(4):
+            if s == 1:
+                with torch.no_grad():
+                    for p_ in model.parameters():
+                        p_.mul_(1.03125)
+            if s == 3:
+                model.load_state_dict(O.keyed_params(cfg, "small"), strict=True)
+            loss = model.forward_loss(x, mask)
+            opt.zero_grad()
+            scaler(loss, opt, clip_grad=None)
+            losses.append(float(loss))
+        model.check_status()
+        runs[early] = (losses, {n: p_.detach().clone() for n, p_ in model.named_parameters()})
+    assert runs[True][0] == runs[False][0]
+    assert len(set(runs[True][0])) == 4             # every write changed the loss: none was missed
+    for n, p_ in runs[True][1].items():
+        assert torch.equal(p_, runs[False][1][n]), n
+
+
 def test_tiny_clipped_training_steps(dev):
     """the clipping branch of the scaler (utils.py:359, clip_grad_norm_) end to end: global norm -> device-side clip factor
     inside the fused AdamW; three steps against the reference's scaler + optimizer (tests/golden/tiny_clip.npz)"""
