@@ -346,7 +346,7 @@ def main():
     dp_ab = None
     if (world > 1 or force_dp) and os.environ.get("MOFO_DP_ROUTE_AB", "1") == "1":
         user = {k: os.environ.get(k) for k in ("MOFO_GEMM_K2", "MOFO_WGRAD_STREAM")}
-        # (default streams since round 6: the decoder's one sliced launch on the side stream, the encoder's groups on the main stream)
+        # (default streams: every weight-gradient launch on the main stream)
         routes = [("k2 on, default streams", {}), ("k2 off, default streams", {"MOFO_GEMM_K2": "0"}),
                   ("k2 on, all weight gradients on the side stream", {"MOFO_WGRAD_STREAM": "side"}),
                   ("k2 off, all weight gradients on the side stream", {"MOFO_GEMM_K2": "0", "MOFO_WGRAD_STREAM": "side"})]

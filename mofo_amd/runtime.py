@@ -828,10 +828,11 @@ class PretrainRuntime:
         # (profiles/r04_wgrad_stream_k2.txt): a CU-filling grouped launch beside the chain slows the chain's kernels by what it hides,
         # and the one-tile-per-CU GEMMs (gemm_k2.h: 128 KiB of LDS) cannot start on a CU that still holds weight-gradient blocks.
         # MOFO_WGRAD_STREAM=side restores the side stream (main_enc / main_dec: per pass).
-        # Round 6: the DECODER's one sliced launch (0.77 ms, nothing of the chain depends on it) goes to the side stream, where it runs beside the
-        # bridge and the first encoder blocks' latency-bound kernels: 11.21 / 11.20 / 11.17 / 11.12 ms (all on main) against 11.13 / 11.12 / 11.15 /
-        # 11.09 (four interleaved pairs, one box); the encoder's groups stay on the main stream.
-        mode = os.environ.get("MOFO_WGRAD_STREAM", "main_enc" if self.wgrad_sliced else "main")
+        # Round 6: the decoder's one sliced launch on the side stream (main_enc) beside the bridge and the first encoder blocks was tried as the
+        # default: 11.13 / 11.12 / 11.15 / 11.09 against 11.21 / 11.20 / 11.17 / 11.12 ms on one box, but 10.615 / 10.576 / 10.571 against
+        # 10.553 / 10.561 / 10.550 on another, and every main-stream kernel it overlaps reads 1.37 x longer in the event brackets and the
+        # kernel trace (dgrad class 45 us per launch instead of 33): everything stays on the main stream.
+        mode = os.environ.get("MOFO_WGRAD_STREAM", "main")
         sliced = self.wgrad_sliced and S is not None and getattr(S, "is_dec", False)
         if mode == "main" or (mode == "main_enc" and n <= 512) or (mode == "main_dec" and n > 512):
             self._wgrad_group(group, sliced)  # same stream: no fork / join events (each costs ~10 us of queue bubble)
