@@ -1174,6 +1174,24 @@ class PretrainRuntime:
         frozen = bool(self.fp8 and getattr(self, "fp8_freeze", False))
         return self.cached(w, ("fwd", getattr(w, "src_u8", False), frozen), lambda: self._forward(w, frozen))
 
+    def fp8_state_dict(self):
+        """the delayed activation scales of the e4m3 forward (one (scale, 1 / scale) pair per site), or None without MOFO_FP8: what a
+        checkpoint has to carry for a resumed run to quantise its first forward like the run that wrote it (utils.save_model).  The
+        weights' e4m3 shadow is not state: the first forward after load_state_dict re-quantises it from the bf16 shadow with exact scales."""
+        if not self.fp8 or not self._fp8_calibrated:
+            return None
+        return {"act_scales": self.act_scales.detach().cpu().clone()}
+
+    def load_fp8_state_dict(self, sd):
+        if not self.fp8 or not sd:
+            return
+        a = sd["act_scales"]
+        if tuple(a.shape) != tuple(self.act_scales.shape):
+            raise ValueError(f"fp8 activation scales: checkpoint has {tuple(a.shape)}, this model {tuple(self.act_scales.shape)}")
+        self.act_scales.copy_(a.to(self.act_scales.dtype))
+        self.act_amax.zero_()
+        self._fp8_calibrated = True      # no calibration forward: the scales are the ones the interrupted run would have used next
+
     def _loss_forward(self, w, normalize_target, grad_scale):
         d = self.d
         if getattr(w, "src_u8", False):

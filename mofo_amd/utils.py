@@ -282,6 +282,10 @@ def save_model(args, epoch, model, model_without_ddp, optimizer, loss_scaler, mo
              'optimizer': optimizer.state_dict(), 'epoch': epoch, 'scaler': loss_scaler.state_dict(), 'args': saved_args}
     if gen is not None and hasattr(gen, "state_dict"):
         state['mask_generator'] = gen.state_dict()
+    rt = getattr(model_without_ddp, "_rt", None)
+    f8 = rt.fp8_state_dict() if rt is not None and hasattr(rt, "fp8_state_dict") else None
+    if f8 is not None:
+        state['fp8'] = f8                      # MOFO_FP8=1: the delayed activation scales (plain tensors; ignored by the reference's loaders)
     save_on_master(state, path)
 
 
@@ -310,4 +314,6 @@ def auto_load_model(args, model, model_without_ddp, optimizer, loss_scaler, mode
         gen = getattr(args, "mask_generator", None)
         if gen is not None and hasattr(gen, "load_state_dict") and 'mask_generator' in state:
             gen.load_state_dict(state['mask_generator'])
+        if 'fp8' in state and hasattr(model_without_ddp, "runtime") and next(model_without_ddp.parameters()).is_cuda:
+            model_without_ddp.runtime().load_fp8_state_dict(state['fp8'])
         print("With optim & sched!")

@@ -1367,6 +1367,52 @@ def test_fp8_shadow_follows_foreign_writes_and_range_updates(dev, monkeypatch):
     assert st.shadow8_current() and consistent(st) < 4e-2
 
 
+def test_fp8_activation_scales_travel_in_the_checkpoint(dev, monkeypatch, tmp_path):
+    """MOFO_FP8=1: utils.save_model writes the delayed activation scales beside the reference's five keys; a resumed model quantises its
+    first forward with them (no calibration forward) and continues within e4m3's resolution of the run that was not interrupted (its
+    weight shadow is re-quantised with exact instead of delayed scales: close, not bit-identical).  Without MOFO_FP8 the key is absent."""
+    import types
+    from mofo_amd import optim_factory, utils
+    from oracle import pretrain_oracle as O
+    cfg = O.OracleConfig(num_frames=4, img_size=64, enc_dim=256, enc_depth=2, enc_heads=4, dec_dim=128, dec_depth=2, dec_heads=2)
+    x = O.keyed_clips(2, cfg).to(dev)
+    np.random.seed(3)
+    mask = torch.from_numpy(np.stack([O.tube_mask(cfg.grid, 0.75)] * 2)).bool().to(dev)
+    monkeypatch.setenv("MOFO_FP8", "1")
+    model, _ = _build(cfg, "xavier", dev)
+    rt = model.runtime()
+    assert rt.fp8 and rt.fp8_state_dict() is None          # nothing to save before the first forward has calibrated the sites
+    opt = optim_factory.create_optimizer(_Args, model)
+    scaler = utils.NativeScalerWithGradNormCount()
+    for _ in range(2):
+        loss = model.forward_loss(x, mask)
+        opt.zero_grad()
+        scaler(loss, opt, clip_grad=None)
+    args = types.SimpleNamespace(output_dir=str(tmp_path), auto_resume=True, resume="", start_epoch=0)
+    utils.save_model(args, 0, model, model, opt, scaler)
+    ck = torch.load(os.path.join(str(tmp_path), "checkpoint-0.pth"), weights_only=False)
+    assert set(ck) == {"model", "optimizer", "epoch", "scaler", "args", "fp8"} and torch.equal(ck["fp8"]["act_scales"], rt.act_scales.cpu())
+    assert type(ck["fp8"]["act_scales"]) is torch.Tensor
+    want = float(model.forward_loss(x, mask))              # the uninterrupted run's third forward
+    model2, _ = _build(cfg, "small", dev)
+    opt2 = optim_factory.create_optimizer(_Args, model2)
+    utils.auto_load_model(args, model2, model2, opt2, utils.NativeScalerWithGradNormCount())
+    rt2 = model2.runtime()
+    assert rt2.fp8 and rt2._fp8_calibrated and torch.equal(rt2.act_scales, ck["fp8"]["act_scales"].to(dev))
+    got = float(model2.forward_loss(x, mask))
+    assert got == pytest.approx(want, rel=2e-2)
+    model2.check_status()
+    # a bf16 run's checkpoint keeps the reference's five keys
+    monkeypatch.setenv("MOFO_FP8", "0")
+    model3, _ = _build(cfg, "xavier", dev)
+    opt3 = optim_factory.create_optimizer(_Args, model3)
+    loss = model3.forward_loss(x, mask)
+    opt3.zero_grad()
+    scaler(loss, opt3, clip_grad=None)
+    utils.save_model(args, 1, model3, model3, opt3, scaler)
+    assert set(torch.load(os.path.join(str(tmp_path), "checkpoint-1.pth"), weights_only=False)) == {"model", "optimizer", "epoch", "scaler", "args"}
+
+
 # ----------------------------------------------------------------------------- "next" rows (SURVEY.md 8f-4)
 def _tiny(mode, dev):
     from oracle import pretrain_oracle as O
